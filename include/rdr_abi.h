@@ -1,0 +1,317 @@
+/*
+ * rdr_abi.h — C ABI of the MI355X visibility-buffer hot path.
+ *
+ * This is the drop-in boundary: the entry points below are what a foreign
+ * function interface on the reference side binds instead of recording the
+ * Vulkan passes through its `lava` backend.  Every struct that crosses the
+ * boundary is byte-for-byte the reference's `#[repr(C)]` / std430 layout, so
+ * a host that already holds the reference's `Scene` can pass pointers to its
+ * vectors without conversion.  Citations are relative to the reference tree.
+ *
+ * Conventions (reference: anyhow::Result everywhere, nothing panics on the
+ * frame path — renderer/src/renderer.rs:862-1002):
+ *   - every fallible call returns int, 0 = success, non-zero = failure, and
+ *     rdr_last_error() returns a thread-local message for the last failure;
+ *   - the caller keeps ownership of every host pointer; rdr_set_scene copies
+ *     everything to HBM and returns after the copy is complete
+ *     (lava/src/device.rs:575-583);
+ *   - one renderer = one GPU = one caller thread (lava's LDevice is
+ *     !Send + !Sync, lava/src/device.rs:87-96).
+ */
+#ifndef RDR_ABI_H
+#define RDR_ABI_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ */
+/* Scene data: layouts of scenery/src/{vertex,mesh}.rs and            */
+/* assets/shaders/mesh.inc.glsl                                        */
+/* ------------------------------------------------------------------ */
+
+/* scenery/src/vertex.rs:4-11, mesh.inc.glsl:8-14 — 64 B */
+typedef struct rdr_vertex {
+    float p[4];  /* position.xyz, w unused            */
+    float n[4];  /* normal.xyz, w unused              */
+    float uv[4]; /* uv0.xy | uv1.zw                   */
+    float t[4];  /* tangent.xyz, w = bitangent sign   */
+} rdr_vertex;
+
+/* scenery/src/mesh.rs:17-28, mesh.inc.glsl:16-28 — 32 B */
+typedef struct rdr_meshlet {
+    float center[3];
+    float radius;
+    int8_t cone_axis[3];
+    int8_t cone_cutoff;
+    uint32_t vertex_offset;   /* into meshlet_vertices              */
+    uint32_t triangle_offset; /* into meshlet_triangles (bytes)     */
+    uint8_t triangle_count;   /* <= 124                             */
+    uint8_t vertex_count;     /* <= 64                              */
+    uint8_t _pad[2];
+} rdr_meshlet;
+
+/* scenery/src/mesh.rs:30-37, mesh.inc.glsl:30-35 — 16 B */
+typedef struct rdr_mesh_lod {
+    uint32_t meshlet_offset;
+    uint32_t meshlet_count;
+    float error;
+    uint32_t _pad;
+} rdr_mesh_lod;
+
+/* scenery/src/mesh.rs:39-49, mesh.inc.glsl:37-45 — 160 B */
+typedef struct rdr_mesh {
+    float center[3];
+    float radius;
+    uint32_t vertex_offset;
+    uint32_t vertex_count;
+    uint32_t lod_count;
+    uint32_t index_offset; /* LOD0 triangle list start in `indices` */
+    rdr_mesh_lod lods[8];
+} rdr_mesh;
+
+/* scenery/src/mesh.rs:61-70, mesh.inc.glsl:47-53 — 16 B */
+typedef struct rdr_mesh_draw {
+    uint32_t alpha_mode; /* 0 = opaque pass, 1 = alpha-mask pass (mesh.rs:11-15) */
+    uint32_t meshlet_visibility_offset;
+    uint32_t model_index;
+    uint16_t mesh_index;
+    uint16_t material_index; /* 0xFFFF = primitive without material (scene.rs:649) */
+} rdr_mesh_draw;
+
+/* scenery/src/mesh.rs:83-123, mesh.inc.glsl:55-92 — 272 B */
+typedef struct rdr_material {
+    float base_color_factor[4];
+    float metallic_roughness_normal_occlusion[4];
+    float emissive_factor_alpha_cutoff[4];
+    float specular_glossiness_factor[4];
+    float clearcoat_factor[4];
+    float sheen_color_roughness_factor[4];
+    float albedo_texture_transform[4];
+    float normal_texture_transform[4];
+    float metallic_roughness_texture_transform[4];
+    float emissive_texture_transform[4];
+    float occlusion_texture_transform[4];
+    float specular_factor[4];
+    uint32_t albedo_texture, albedo_texture_uv;
+    uint32_t normal_texture, normal_texture_uv;
+    uint32_t metallic_roughness_texture, metallic_roughness_texture_uv;
+    uint32_t emissive_texture, emissive_texture_uv;
+    uint32_t occlusion_texture, occlusion_texture_uv;
+    uint32_t clearcoat_texture, clearcoat_texture_uv;
+    uint32_t specular_color_texture, specular_color_texture_uv;
+    uint32_t specular_texture, specular_texture_uv;
+    float ior;
+    uint32_t alpha_mode;
+    uint32_t material_type; /* RDR_MAT_* bits */
+    uint32_t _pad;
+} rdr_material;
+
+/* scenery/src/mesh.rs:72-81, mesh.inc.glsl:129-133 */
+#define RDR_MAT_METAL_ROUGHNESS 1u
+#define RDR_MAT_SPEC_GLOSS (1u << 1)
+#define RDR_MAT_CLEARCOAT (1u << 2)
+#define RDR_MAT_SHEEN (1u << 3)
+#define RDR_MAT_SPEC (1u << 4)
+
+#define RDR_NO_TEXTURE 0xFFFFFFFFu
+
+/* renderer/src/renderer.rs:56-76, mesh.inc.glsl:104-122 — 288 B.
+ * Matrices are column-major (glam Mat4 == GLSL mat4): m[col*4 + row]. */
+typedef struct rdr_ubo {
+    float view_proj[16];
+    float view[16];
+    float proj[16];
+    float camera_position[3];
+    uint32_t _pad0;
+    float near_plane;
+    float far_plane;
+    float depth_pyramid_width;
+    float depth_pyramid_height;
+    float frustum[4];
+    uint32_t draw_count;
+    uint32_t lod_enabled;
+    uint32_t cull_enabled;
+    float lod_target;
+    float screen_width;
+    float screen_height;
+    uint32_t _pad1[2];
+    float sun_direction[4];
+} rdr_ubo;
+
+/* ------------------------------------------------------------------ */
+/* Textures.  The reference loads files (renderer/src/renderer/        */
+/* image_loader.rs) into Vulkan images; the boundary takes the decoded */
+/* texels instead, with the colour-space choice the loader made        */
+/* (image_loader.rs:47-51,164-168).                                    */
+/* ------------------------------------------------------------------ */
+#define RDR_FORMAT_RGBA8_UNORM 0u
+#define RDR_FORMAT_RGBA8_SRGB 1u
+#define RDR_FORMAT_RGBA32F 2u
+
+/* 2D image: mip levels tightly packed, level 0 first, rows top to bottom;
+ * level i is max(1,width>>i) x max(1,height>>i). */
+typedef struct rdr_image_desc {
+    const void* data;
+    uint32_t width, height;
+    uint32_t mip_count;
+    uint32_t format;
+} rdr_image_desc;
+
+/* Cubemap: mip-major; within a mip the six faces in Vulkan layer order
+ * +X,-X,+Y,-Y,+Z,-Z; level i is max(1,size>>i) square. */
+typedef struct rdr_cubemap_desc {
+    const void* data;
+    uint32_t size;
+    uint32_t mip_count;
+    uint32_t format;
+    uint32_t _pad;
+} rdr_cubemap_desc;
+
+/* scenery/src/scene.rs:27-33 (EnvMap), bound at renderer/src/renderer/pass.rs:539-558 */
+typedef struct rdr_env_desc {
+    rdr_image_desc brdf_lut;
+    rdr_cubemap_desc skybox; /* accepted, not sampled by this path */
+    rdr_cubemap_desc lambertian;
+    rdr_cubemap_desc ggx;
+    rdr_cubemap_desc charlie;
+} rdr_env_desc;
+
+/* The arrays SceneResources::load_scene uploads (renderer/src/renderer.rs:426-586). */
+typedef struct rdr_scene_desc {
+    const rdr_vertex* vertices;
+    const uint32_t* indices; /* all meshes' LOD0 triangle lists, mesh-local vertex ids */
+    const uint32_t* meshlet_vertices;
+    const uint8_t* meshlet_triangles;
+    const rdr_meshlet* meshlets;
+    const rdr_mesh* meshes;
+    const rdr_mesh_draw* mesh_draws;
+    const rdr_material* materials;
+    const float* global_transforms; /* transform_count column-major mat4 */
+    const rdr_image_desc* images;   /* images[i] is texture index i of the materials */
+    const rdr_env_desc* env;        /* NULL: black environment, zero BRDF LUT */
+    uint32_t vertex_count;
+    uint32_t index_count;
+    uint32_t meshlet_vertex_count;
+    uint32_t meshlet_triangle_bytes;
+    uint32_t meshlet_count;
+    uint32_t mesh_count;
+    uint32_t draw_count;
+    uint32_t material_count;
+    uint32_t transform_count;
+    uint32_t image_count;
+    uint32_t meshlet_visibility_count; /* scenery/src/scene.rs:648-651 */
+    uint32_t _pad;
+} rdr_scene_desc;
+
+/* scenery/src/lib.rs:7-14 (RendererConfig); only the two fields that reach
+ * the GPU (renderer/src/renderer.rs:1182-1183) plus this path's own switches. */
+typedef struct rdr_config {
+    uint32_t lod_enabled;
+    uint32_t cull_enabled;   /* accepted; occlusion culling is result-neutral and not run */
+    uint32_t collect_stats;  /* 1: count triangles/fragments per frame (small cost) */
+    uint32_t time_kernels;   /* 1: bracket each kernel with events for rdr_get_stats */
+} rdr_config;
+
+/* Packed visibility-buffer key written by the rasteriser with a 64-bit
+ * atomic min:
+ *   bits 62..32  0x7FFFFFFF - float_bits(depth)   depth = reverse-Z z/w in [0,1]
+ *   bits 31..7   meshlet instance = draw.meshlet_visibility_offset + (meshlet - lod.meshlet_offset)
+ *   bits  6..0   triangle index inside the meshlet (<= 123)
+ * Bit 63 is never set, so signed and unsigned 64-bit min agree on every key. */
+#define RDR_VIS_CLEAR 0x7FFFFFFFFFFFFFFFull
+
+#define RDR_STAT_KERNELS 8
+enum {
+    RDR_K_CLEAR = 0,
+    RDR_K_DRAW_CULL = 1,
+    RDR_K_MESHLET_CULL = 2,
+    RDR_K_RASTER = 3,
+    RDR_K_CLIP_SETUP = 4,
+    RDR_K_BIG_RASTER = 5,
+    RDR_K_SHADE = 6,
+    RDR_K_RESOLVE = 7
+};
+
+typedef struct rdr_stats {
+    float kernel_ms[RDR_STAT_KERNELS]; /* last frame, valid when time_kernels = 1 */
+    uint64_t draws_visible;
+    uint64_t commands;            /* 64-meshlet cull commands emitted */
+    uint64_t meshlets_tested;
+    uint64_t meshlets_visible;
+    uint64_t triangles_submitted; /* sum over visible draws of the selected LOD's triangles */
+    uint64_t triangles_tested;    /* triangles of visible meshlets */
+    uint64_t triangles_rasterised;/* survived backface + small-triangle tests */
+    uint64_t triangles_big;       /* routed to the clip / tile path */
+    uint64_t fragments;           /* 64-bit atomics issued to memory */
+    uint64_t pixels_covered;      /* filled by rdr_shade */
+} rdr_stats;
+
+typedef struct rdr_renderer rdr_renderer;
+
+/* Replaces Renderer::new (renderer/src/renderer.rs:793).  hip_devices[0] is
+ * the GPU this renderer owns; n_devices must be 1 (one process per GPU). */
+int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height,
+               const int* hip_devices, int n_devices, rdr_renderer** out);
+
+/* Replaces Renderer::set_scene (renderer.rs:1004) / SceneResources::load_scene
+ * (renderer.rs:426-698): validates, uploads, builds the shadow-ray BVH. */
+int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene);
+
+/* Replaces SceneResources::upload_transforms (renderer.rs:700-722): the whole array. */
+int rdr_update_transforms(rdr_renderer* r, const float* mat4s, uint32_t count);
+
+/* Replaces Renderer::render (renderer.rs:862): UBO update (renderer.rs:1148-1197)
+ * then cull -> raster -> shade -> sRGB store, in the order of renderer.rs:803-843. */
+int rdr_render(rdr_renderer* r, const float cam_pos[3], const float cam_dir[3],
+               const float sun_dir[3]);
+
+/* The two halves of rdr_render, for sort-last rendering: geometry into the
+ * 64-bit visibility buffer, (composite by the caller), then shading. */
+int rdr_render_visbuffer(rdr_renderer* r, const float cam_pos[3], const float cam_dir[3],
+                         const float sun_dir[3]);
+int rdr_shade(rdr_renderer* r);
+
+/* Sort-last share of this renderer: meshlet instances [lo, hi) of the scene's
+ * meshlet_visibility_count.  Default is everything. */
+int rdr_set_partition(rdr_renderer* r, uint32_t instance_lo, uint32_t instance_hi);
+
+/* Shading restricted to rows [row_lo, row_hi) (after a reduce-scatter). Default all. */
+int rdr_set_shade_rows(rdr_renderer* r, uint32_t row_lo, uint32_t row_hi);
+
+/* Device addresses of the W*H uint64 visibility buffer and the W*H*4 RGBA8
+ * image, for the collective that composites them (RCCL through the caller). */
+void* rdr_visbuffer_device_ptr(rdr_renderer* r);
+void* rdr_color_device_ptr(rdr_renderer* r);
+
+/* Run on the caller's HIP stream (hipStream_t) instead of the library's own. */
+int rdr_set_stream(rdr_renderer* r, void* hip_stream);
+int rdr_sync(rdr_renderer* r);
+
+/* The reference never reads pixels back; these are the readback entry points
+ * the replacement adds.  out_xy: W*H*2 uint32 in the reference's texel format
+ * (x = meshlet_index << 8 | triangle, y = draw_id; 0xFFFFFFFF twice = no
+ * geometry; assets/shaders/shader.frag.glsl:71-74, pass.rs:250). */
+int rdr_read_visbuffer(rdr_renderer* r, uint32_t* out_xy);
+int rdr_read_visbuffer_u64(rdr_renderer* r, uint64_t* out);
+/* W*H*4 bytes, row 0 = top, sRGB-encoded as an *_SRGB swapchain image stores
+ * it (lava/src/swapchain.rs:100-115). */
+int rdr_read_color(rdr_renderer* r, uint8_t* out_rgba8_srgb);
+int rdr_get_stats(rdr_renderer* r, rdr_stats* out);
+
+/* Renderer::update_uniform_object (renderer.rs:1148-1197) on its own. */
+int rdr_build_ubo(uint32_t width, uint32_t height, const float cam_pos[3],
+                  const float cam_dir[3], const float sun_dir[3], uint32_t draw_count,
+                  uint32_t lod_enabled, uint32_t cull_enabled, rdr_ubo* out);
+int rdr_get_ubo(rdr_renderer* r, rdr_ubo* out);
+
+void rdr_destroy(rdr_renderer* r);
+const char* rdr_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RDR_ABI_H */

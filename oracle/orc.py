@@ -1,0 +1,106 @@
+"""ctypes binding of the CPU oracle (``oracle/liborc.so``).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of bench.py; the ``renderer_amd`` package never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from renderer_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liborc.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        f3 = C.POINTER(C.c_float)
+        L.orc_build_ubo.argtypes = [C.c_uint32, C.c_uint32, f3, f3, f3, C.c_uint32, C.c_uint32, C.c_uint32,
+                                    C.POINTER(abi.Ubo)]
+        L.orc_build_ubo.restype = None
+        L.orc_render_visbuffer.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.Ubo), C.c_uint32, C.c_uint32,
+                                           C.c_void_p, C.c_void_p, C.POINTER(abi.Stats)]
+        L.orc_resolve.argtypes = [C.POINTER(abi.SceneDesc), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_shade.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.Ubo), C.c_void_p, C.c_void_p, C.c_uint32,
+                                C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_num_threads.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def build_ubo(width, height, cam_pos, cam_dir, sun_dir, draw_count, lod_enabled=False, cull_enabled=True):
+    u = abi.Ubo()
+    lib().orc_build_ubo(width, height, _f3(cam_pos), _f3(cam_dir), _f3(sun_dir), draw_count,
+                        int(lod_enabled), int(cull_enabled), C.byref(u))
+    return u
+
+
+class OracleRenderer:
+    """Same call shape as ``renderer_amd.Renderer`` (new / set_scene / render), on the CPU."""
+
+    def __init__(self, width, height, config=None):
+        self.width, self.height = width, height
+        self.lod_enabled = bool(config.lod_enabled) if config else False
+        self.cull_enabled = bool(config.cull_enabled) if config else True
+        self.part = (0, 0xFFFFFFFF)
+        self.stats = abi.Stats()
+
+    def set_scene(self, scene):
+        self.scene = scene
+        self.desc, self._keep = scene.to_desc()
+        self.draw_lod = np.zeros(max(1, len(scene.mesh_draws)), np.uint8)
+
+    def set_partition(self, lo, hi):
+        self.part = (lo, hi)
+
+    def render_visbuffer(self, camera=None, sun=None):
+        cam = camera or self.scene.camera
+        sun = sun or self.scene.sun_direction
+        self.ubo = build_ubo(self.width, self.height, cam.position, cam.direction, sun,
+                             len(self.scene.mesh_draws), self.lod_enabled, self.cull_enabled)
+        self.vis = np.empty(self.width * self.height, np.uint64)
+        rc = lib().orc_render_visbuffer(C.byref(self.desc), C.byref(self.ubo), self.part[0], self.part[1],
+                                        self.vis.ctypes.data, self.draw_lod.ctypes.data, C.byref(self.stats))
+        assert rc == 0
+        return self.vis.reshape(self.height, self.width)
+
+    def shade(self, vis=None, rows=None, want_linear=False):
+        vis = self.vis if vis is None else np.ascontiguousarray(vis, np.uint64).reshape(-1)
+        rows = rows or (0, self.height)
+        out = np.zeros((self.height, self.width, 4), np.uint8)
+        lin = np.zeros((self.height, self.width, 4), np.float32) if want_linear else None
+        rc = lib().orc_shade(C.byref(self.desc), C.byref(self.ubo), vis.ctypes.data, self.draw_lod.ctypes.data,
+                             rows[0], rows[1], out.ctypes.data, lin.ctypes.data if want_linear else None)
+        assert rc == 0
+        return (out, lin) if want_linear else out
+
+    def render(self, camera=None, sun=None):
+        self.render_visbuffer(camera, sun)
+        return self.shade()
+
+    def read_visbuffer(self, vis=None):
+        vis = self.vis if vis is None else np.ascontiguousarray(vis, np.uint64).reshape(-1)
+        out = np.zeros((self.height, self.width, 2), np.uint32)
+        lib().orc_resolve(C.byref(self.desc), self.width, self.height, vis.ctypes.data,
+                          self.draw_lod.ctypes.data, out.ctypes.data)
+        return out
+
+
+def num_threads():
+    return int(lib().orc_num_threads())

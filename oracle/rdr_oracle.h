@@ -1,0 +1,42 @@
+/*
+ * rdr_oracle.h — entry points of the CPU oracle (liborc.so).
+ *
+ * TEST INFRASTRUCTURE ONLY: a CPU restatement of the reference's per-frame
+ * path used to check the HIP kernels and as the timed CPU baseline.  The
+ * shipped library never links, loads or calls it.
+ */
+#ifndef RDR_ORACLE_H
+#define RDR_ORACLE_H
+
+#include "../include/rdr_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+void orc_build_ubo(uint32_t width, uint32_t height, const float cam_pos[3], const float cam_dir[3],
+                   const float sun_dir[3], uint32_t draw_count, uint32_t lod_enabled,
+                   uint32_t cull_enabled, rdr_ubo* out);
+
+/* Cull + transform + rasterise meshlet instances [part_lo, part_hi) into
+ * vis[W*H] (cleared here).  draw_lod[draw_count] receives the LOD each draw
+ * selected, 0xFF for draws that emitted nothing. */
+int orc_render_visbuffer(const rdr_scene_desc* scene, const rdr_ubo* ubo, uint32_t part_lo,
+                         uint32_t part_hi, uint64_t* vis, uint8_t* draw_lod, rdr_stats* stats);
+
+int orc_resolve(const rdr_scene_desc* scene, uint32_t width, uint32_t height, const uint64_t* vis,
+                const uint8_t* draw_lod, uint32_t* out_xy);
+
+/* Deferred shading + sRGB store of rows [row_lo, row_hi).  out_rgba8 is W*H*4
+ * (row 0 = top); out_linear, when not NULL, receives W*H*4 floats before the
+ * sRGB encode. */
+int orc_shade(const rdr_scene_desc* scene, const rdr_ubo* ubo, const uint64_t* vis,
+              const uint8_t* draw_lod, uint32_t row_lo, uint32_t row_hi, uint8_t* out_rgba8,
+              float* out_linear);
+
+int orc_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,620 @@
+// rdr_api.hip — the C ABI of include/rdr_abi.h: renderer state, scene upload,
+// frame submission and readback.
+//
+// Mirrors the reference's Renderer (renderer/src/renderer.rs:780-1060):
+//   rdr_create            Renderer::new              :793
+//   rdr_set_scene         SceneResources::load_scene :426-698
+//   rdr_update_transforms upload_transforms          :700-722
+//   rdr_render            Renderer::render           :862-1002 with the pass order of :803-843
+//   rdr_build_ubo         update_uniform_object      :1148-1197
+// There is no CPU fallback: every entry point needs a HIP device.
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "rdr_internal.h"
+
+static thread_local std::string g_last_error;
+void rdr_set_error(const std::string& msg) { g_last_error = msg; }
+extern "C" const char* rdr_last_error(void) { return g_last_error.c_str(); }
+
+namespace {
+
+template <typename T>
+struct DeviceBuffer {
+    T* ptr = nullptr;
+    size_t count = 0;
+    ~DeviceBuffer() { release(); }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        count = 0;
+    }
+    int alloc(size_t n) {
+        release();
+        count = n;
+        RDR_HIP(hipMalloc(reinterpret_cast<void**>(&ptr), std::max<size_t>(n, 1) * sizeof(T)));
+        return 0;
+    }
+    int upload(const T* src, size_t n) {
+        if (alloc(n)) return 1;
+        if (n) RDR_HIP(hipMemcpy(ptr, src, n * sizeof(T), hipMemcpyHostToDevice));
+        return 0;
+    }
+};
+
+uint32_t mip_dim(uint32_t d, uint32_t l) {
+    const uint32_t v = d >> l;
+    return v ? v : 1u;
+}
+size_t texel_bytes(uint32_t format) { return format == RDR_FORMAT_RGBA32F ? 16 : 4; }
+
+} // namespace
+
+struct rdr_renderer {
+    rdr_config cfg{};
+    uint32_t width = 0, height = 0;
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t events[8]{};
+    bool has_events = false;
+    bool frame_rendered = false;
+
+    // frame resources
+    DeviceBuffer<unsigned long long> vis;
+    DeviceBuffer<uint8_t> color;
+    DeviceBuffer<FrameCounters> counters;
+    DeviceBuffer<CullCommand> commands;
+    DeviceBuffer<VisibleMeshlet> visible;
+    DeviceBuffer<DeferredTriangle> deferred;
+    DeviceBuffer<uint32_t> resolve_out;
+    DeviceBuffer<float> srgb_lut;
+
+    // scene resources
+    DeviceBuffer<rdr_vertex> vertices;
+    DeviceBuffer<float> pos_x, pos_y, pos_z;
+    DeviceBuffer<uint32_t> meshlet_vertices;
+    DeviceBuffer<uint8_t> meshlet_triangles;
+    DeviceBuffer<rdr_meshlet> meshlets;
+    DeviceBuffer<rdr_mesh> meshes;
+    DeviceBuffer<rdr_mesh_draw> draws;
+    DeviceBuffer<rdr_material> materials;
+    DeviceBuffer<float> transforms;
+    DeviceBuffer<uint32_t> instance_draw;
+    DeviceBuffer<uint8_t> draw_lod;
+    DeviceBuffer<GpuImage> images;
+    DeviceBuffer<uint8_t> texels;
+    DeviceBuffer<BvhNode> tlas, blas;
+    DeviceBuffer<uint32_t> tlas_items;
+    DeviceBuffer<float> blas_tris;
+    DeviceBuffer<GpuInstance> instances;
+
+    // host copies needed to rebuild the TLAS when transforms change
+    std::vector<rdr_mesh_draw> h_draws;
+    std::vector<rdr_mesh> h_meshes;
+    HostBvh bvh;
+    bool has_scene = false;
+
+    SceneView sv{};
+    rdr_ubo ubo{};
+    uint32_t part_lo = 0, part_hi = 0xFFFFFFFFu;
+    uint32_t row_lo = 0, row_hi = 0xFFFFFFFFu;
+    uint32_t meshlet_visibility_count = 0;
+    rdr_stats stats{};
+};
+
+namespace {
+
+// ---- UBO -------------------------------------------------------------------------
+struct V3 {
+    float x, y, z;
+};
+V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+// glam Vec3::normalize(): multiply by the reciprocal of the length
+V3 normalize_recip(V3 a) {
+    const float r = 1.0f / std::sqrt(dot(a, a));
+    return {a.x * r, a.y * r, a.z * r};
+}
+uint32_t power_2_floor(uint32_t x) { // renderer/src/math.rs:17-25
+    uint32_t r = 1;
+    while (r * 2 < x) r *= 2;
+    return r;
+}
+
+void build_ubo(uint32_t width, uint32_t height, const float* cam_pos, const float* cam_dir, const float* sun_dir,
+               uint32_t draw_count, uint32_t lod_enabled, uint32_t cull_enabled, rdr_ubo* u) {
+    std::memset(u, 0, sizeof(*u));
+    const V3 eye{cam_pos[0], cam_pos[1], cam_pos[2]};
+    // Camera::view_mat = look_to_lh(position, -direction, Y) (scenery/src/camera.rs:12-14);
+    // glam's look_to_lh(e, d, up) is look_to_rh(e, -d, up), so the forward axis is +direction.
+    const V3 f = normalize_recip(V3{cam_dir[0], cam_dir[1], cam_dir[2]});
+    const V3 s = normalize_recip(cross(f, V3{0.0f, 1.0f, 0.0f}));
+    const V3 v = cross(s, f);
+    float* V = u->view;
+    V[0] = s.x; V[1] = v.x; V[2] = -f.x;
+    V[4] = s.y; V[5] = v.y; V[6] = -f.y;
+    V[8] = s.z; V[9] = v.z; V[10] = -f.z;
+    V[12] = -dot(eye, s); V[13] = -dot(eye, v); V[14] = dot(eye, f); V[15] = 1.0f;
+
+    // perspective_infinite_reverse_lh(45 deg, aspect, 0.01) then proj[0][0] *= -1 (renderer.rs:1160-1167)
+    const float near_plane = 0.01f;
+    const float fov = 45.0f * (3.14159265358979323846f / 180.0f);
+    const float aspect = (float)width / (float)height;
+    const float sn = std::sin(0.5f * fov), cs = std::cos(0.5f * fov);
+    const float h = cs / sn;
+    const float w = h / aspect;
+    float* P = u->proj;
+    P[0] = -w; P[5] = h; P[11] = 1.0f; P[14] = near_plane;
+
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r)
+            u->view_proj[c * 4 + r] =
+                ((P[0 * 4 + r] * V[c * 4 + 0] + P[1 * 4 + r] * V[c * 4 + 1]) + P[2 * 4 + r] * V[c * 4 + 2]) + P[3 * 4 + r] * V[c * 4 + 3];
+
+    u->camera_position[0] = eye.x; u->camera_position[1] = eye.y; u->camera_position[2] = eye.z;
+    // normalize_plane(row3 + row0), normalize_plane(row3 + row1) (renderer.rs:1171-1177, math.rs:3-5)
+    float fx[3], fy[3];
+    for (int c = 0; c < 3; ++c) {
+        fx[c] = P[c * 4 + 3] + P[c * 4 + 0];
+        fy[c] = P[c * 4 + 3] + P[c * 4 + 1];
+    }
+    const float lx = std::sqrt(dot(V3{fx[0], fx[1], fx[2]}, V3{fx[0], fx[1], fx[2]}));
+    const float ly = std::sqrt(dot(V3{fy[0], fy[1], fy[2]}, V3{fy[0], fy[1], fy[2]}));
+    u->frustum[0] = fx[0] / lx; u->frustum[1] = fx[2] / lx;
+    u->frustum[2] = fy[1] / ly; u->frustum[3] = fy[2] / ly;
+    u->near_plane = near_plane;
+    u->far_plane = 500.0f;
+    u->lod_enabled = lod_enabled ? 1u : 0u;
+    u->cull_enabled = cull_enabled ? 1u : 0u;
+    u->draw_count = draw_count;
+    u->depth_pyramid_width = (float)power_2_floor(width);
+    u->depth_pyramid_height = (float)power_2_floor(height);
+    u->lod_target = (1.0f / P[5]) * (1.0f / (float)height);
+    u->screen_width = (float)width;
+    u->screen_height = (float)height;
+    u->sun_direction[0] = sun_dir[0]; u->sun_direction[1] = sun_dir[1]; u->sun_direction[2] = sun_dir[2];
+}
+
+// ---- scene validation ---------------------------------------------------------------
+int validate_scene(const rdr_scene_desc& s) {
+    RDR_CHECK(s.draw_count == 0 || (s.mesh_draws && s.meshes && s.global_transforms), "scene: null draw/mesh/transform array");
+    RDR_CHECK(s.meshlet_count == 0 || (s.meshlets && s.meshlet_vertices && s.meshlet_triangles && s.vertices), "scene: null geometry array");
+    RDR_CHECK(s.meshlet_visibility_count < (1u << 25), "scene: more than 2^25 meshlet instances do not fit the 32-bit triangle id");
+    for (uint32_t mi = 0; mi < s.mesh_count; ++mi) {
+        const rdr_mesh& m = s.meshes[mi];
+        RDR_CHECK(m.lod_count >= 1 && m.lod_count <= 8, "scene: mesh lod_count out of range");
+        RDR_CHECK((uint64_t)m.vertex_offset + m.vertex_count <= s.vertex_count, "scene: mesh vertex range out of bounds");
+        RDR_CHECK(m.index_offset <= s.index_count, "scene: mesh index_offset out of bounds");
+        if (mi + 1 < s.mesh_count) RDR_CHECK(s.meshes[mi + 1].index_offset >= m.index_offset, "scene: mesh index_offset not monotone");
+        for (uint32_t l = 0; l < m.lod_count; ++l) {
+            const rdr_mesh_lod& L = m.lods[l];
+            RDR_CHECK((uint64_t)L.meshlet_offset + L.meshlet_count <= s.meshlet_count, "scene: lod meshlet range out of bounds");
+            RDR_CHECK(L.meshlet_count <= m.lods[0].meshlet_count, "scene: a coarser lod has more meshlets than lod 0");
+            for (uint32_t k = 0; k < L.meshlet_count; ++k) {
+                const rdr_meshlet& ml = s.meshlets[L.meshlet_offset + k];
+                RDR_CHECK(ml.vertex_count <= 64 && ml.triangle_count <= 124, "scene: meshlet exceeds 64 vertices / 124 triangles");
+                RDR_CHECK((uint64_t)ml.vertex_offset + ml.vertex_count <= s.meshlet_vertex_count, "scene: meshlet vertex range out of bounds");
+                RDR_CHECK((uint64_t)ml.triangle_offset + 3u * ml.triangle_count <= s.meshlet_triangle_bytes, "scene: meshlet triangle range out of bounds");
+                for (uint32_t v = 0; v < ml.vertex_count; ++v)
+                    RDR_CHECK(s.meshlet_vertices[ml.vertex_offset + v] < m.vertex_count, "scene: meshlet vertex id outside its mesh");
+                for (uint32_t b = 0; b < 3u * ml.triangle_count; ++b)
+                    RDR_CHECK(s.meshlet_triangles[ml.triangle_offset + b] < ml.vertex_count, "scene: meshlet triangle index outside the meshlet");
+            }
+        }
+        const uint32_t end = mi + 1 < s.mesh_count ? s.meshes[mi + 1].index_offset : s.index_count;
+        for (uint32_t i = m.index_offset; i < end; ++i) RDR_CHECK(s.indices[i] < m.vertex_count, "scene: index outside its mesh");
+    }
+    uint32_t expect = 0;
+    for (uint32_t di = 0; di < s.draw_count; ++di) {
+        const rdr_mesh_draw& d = s.mesh_draws[di];
+        RDR_CHECK(d.mesh_index < s.mesh_count, "scene: draw mesh_index out of bounds");
+        RDR_CHECK(d.model_index < s.transform_count, "scene: draw model_index out of bounds");
+        RDR_CHECK(d.alpha_mode <= 1, "scene: draw alpha_mode must be 0 (opaque) or 1 (mask)");
+        RDR_CHECK(d.meshlet_visibility_offset >= expect, "scene: meshlet_visibility_offset ranges overlap or are not in draw order");
+        expect = d.meshlet_visibility_offset + s.meshes[d.mesh_index].lods[0].meshlet_count;
+        RDR_CHECK(expect >= d.meshlet_visibility_offset, "scene: meshlet_visibility_offset overflow");
+    }
+    RDR_CHECK(expect <= s.meshlet_visibility_count, "scene: meshlet_visibility_count smaller than the draws need");
+    for (uint32_t i = 0; i < s.image_count; ++i) {
+        const rdr_image_desc& im = s.images[i];
+        if (!im.data) continue;
+        RDR_CHECK(im.width && im.height && im.mip_count >= 1 && im.mip_count <= 17, "scene: image dimensions / mip count invalid");
+        RDR_CHECK(im.format <= RDR_FORMAT_RGBA32F, "scene: unknown image format");
+    }
+    return 0;
+}
+
+struct TexelPacker {
+    std::vector<uint8_t> blob;
+    size_t append(const void* src, size_t bytes) {
+        const size_t off = (blob.size() + 255) & ~(size_t)255;
+        blob.resize(off + bytes);
+        if (bytes) std::memcpy(blob.data() + off, src, bytes);
+        return off;
+    }
+};
+
+GpuImage pack_image(TexelPacker& tp, const rdr_image_desc& im) {
+    GpuImage g{};
+    if (!im.data) return g; // mip_count 0: samples as zero
+    g.width = im.width; g.height = im.height; g.mip_count = im.mip_count; g.format = im.format;
+    size_t bytes = 0;
+    for (uint32_t l = 0; l < im.mip_count; ++l) {
+        g.level_offset[l] = (uint32_t)bytes;
+        bytes += (size_t)mip_dim(im.width, l) * mip_dim(im.height, l) * texel_bytes(im.format);
+    }
+    g.offset = tp.append(im.data, bytes);
+    return g;
+}
+
+int pack_cubemap(TexelPacker& tp, const rdr_cubemap_desc* cm, GpuCubemap* out) {
+    static const uint8_t black[24] = {0};
+    GpuCubemap g{};
+    if (!cm || !cm->data) {
+        g.size = 1; g.mip_count = 1; g.format = RDR_FORMAT_RGBA8_UNORM;
+        g.offset = tp.append(black, sizeof(black));
+        *out = g;
+        return 0;
+    }
+    RDR_CHECK(cm->size && cm->mip_count >= 1 && cm->mip_count <= 17, "scene: cubemap dimensions / mip count invalid");
+    RDR_CHECK(cm->format == RDR_FORMAT_RGBA8_UNORM || cm->format == RDR_FORMAT_RGBA32F, "scene: cubemap format must be RGBA8_UNORM or RGBA32F");
+    g.size = cm->size; g.mip_count = cm->mip_count; g.format = cm->format;
+    size_t bytes = 0;
+    for (uint32_t l = 0; l < cm->mip_count; ++l) {
+        g.level_offset[l] = (uint32_t)bytes;
+        const size_t n = mip_dim(cm->size, l);
+        bytes += 6 * n * n * texel_bytes(cm->format);
+    }
+    g.offset = tp.append(cm->data, bytes);
+    *out = g;
+    return 0;
+}
+
+int upload_tlas(rdr_renderer* r) {
+    if (r->tlas.upload(r->bvh.tlas_nodes.data(), r->bvh.tlas_nodes.size())) return 1;
+    if (r->tlas_items.upload(r->bvh.tlas_items.data(), r->bvh.tlas_items.size())) return 1;
+    if (r->instances.upload(r->bvh.instances.data(), r->bvh.instances.size())) return 1;
+    r->sv.tlas = r->tlas.ptr;
+    r->sv.tlas_items = r->tlas_items.ptr;
+    r->sv.instances = r->instances.ptr;
+    return 0;
+}
+
+FrameView make_frame_view(rdr_renderer* r) {
+    FrameView fv{};
+    fv.ubo = r->ubo;
+    fv.vis = r->vis.ptr;
+    fv.color = r->color.ptr;
+    fv.commands = r->commands.ptr;
+    fv.visible = r->visible.ptr;
+    fv.deferred = r->deferred.ptr;
+    fv.counters = r->counters.ptr;
+    fv.width = r->width; fv.height = r->height;
+    fv.part_lo = r->part_lo; fv.part_hi = r->part_hi;
+    fv.row_lo = std::min(r->row_lo, r->height);
+    fv.row_hi = std::min(r->row_hi, r->height);
+    fv.command_capacity = (uint32_t)r->commands.count;
+    fv.visible_capacity = (uint32_t)r->visible.count;
+    fv.deferred_capacity = (uint32_t)r->deferred.count;
+    fv.collect_stats = r->cfg.collect_stats;
+    return fv;
+}
+
+int fetch_counters(rdr_renderer* r, FrameCounters* out) {
+    RDR_HIP(hipStreamSynchronize(r->stream));
+    RDR_HIP(hipMemcpy(out, r->counters.ptr, sizeof(FrameCounters), hipMemcpyDeviceToHost));
+    RDR_CHECK(out->deferred_overflow == 0, "frame: the deferred-triangle list overflowed; triangles were dropped");
+    RDR_CHECK(out->cmd_count <= r->commands.count && out->vis_count <= r->visible.count, "frame: a work list overflowed");
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int rdr_build_ubo(uint32_t width, uint32_t height, const float cam_pos[3], const float cam_dir[3],
+                  const float sun_dir[3], uint32_t draw_count, uint32_t lod_enabled, uint32_t cull_enabled, rdr_ubo* out) {
+    RDR_CHECK(out && cam_pos && cam_dir && sun_dir && width && height, "rdr_build_ubo: bad argument");
+    build_ubo(width, height, cam_pos, cam_dir, sun_dir, draw_count, lod_enabled, cull_enabled, out);
+    return 0;
+}
+
+int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int* hip_devices, int n_devices, rdr_renderer** out) {
+    RDR_CHECK(out, "rdr_create: out is null");
+    *out = nullptr;
+    RDR_CHECK(width >= 1 && height >= 1 && width <= 16384 && height <= 16384, "rdr_create: extent must be within 1..16384");
+    RDR_CHECK(n_devices == 1 && hip_devices, "rdr_create: exactly one HIP device per renderer (one process per GPU)");
+    int count = 0;
+    RDR_HIP(hipGetDeviceCount(&count));
+    RDR_CHECK(count > 0, "rdr_create: no HIP device available; this library has no CPU path");
+    RDR_CHECK(hip_devices[0] >= 0 && hip_devices[0] < count, "rdr_create: HIP device index out of range");
+    std::unique_ptr<rdr_renderer> r(new rdr_renderer());
+    if (cfg) r->cfg = *cfg;
+    r->width = width; r->height = height; r->device = hip_devices[0];
+    RDR_HIP(hipSetDevice(r->device));
+    RDR_HIP(hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking));
+    r->stream = r->own_stream;
+    for (auto& e : r->events) RDR_HIP(hipEventCreate(&e));
+    r->has_events = true;
+    const size_t npx = (size_t)width * height;
+    if (r->vis.alloc(npx) || r->color.alloc(npx * 4) || r->counters.alloc(1)) return 1;
+    RDR_HIP(hipMemset(r->counters.ptr, 0, sizeof(FrameCounters)));
+    float lut[256];
+    for (int i = 0; i < 256; ++i) {
+        const float c = (float)i / 255.0f;
+        lut[i] = c <= 0.04045f ? c / 12.92f : std::pow((c + 0.055f) / 1.055f, 2.4f);
+    }
+    if (r->srgb_lut.upload(lut, 256)) return 1;
+    *out = r.release();
+    return 0;
+}
+
+void rdr_destroy(rdr_renderer* r) {
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    (void)hipStreamSynchronize(r->stream);
+    if (r->has_events)
+        for (auto& e : r->events) (void)hipEventDestroy(e);
+    if (r->own_stream) (void)hipStreamDestroy(r->own_stream);
+    delete r;
+}
+
+int rdr_set_stream(rdr_renderer* r, void* hip_stream) {
+    RDR_CHECK(r, "rdr_set_stream: renderer is null");
+    RDR_HIP(hipStreamSynchronize(r->stream));
+    r->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : r->own_stream;
+    return 0;
+}
+
+int rdr_sync(rdr_renderer* r) {
+    RDR_CHECK(r, "rdr_sync: renderer is null");
+    RDR_HIP(hipStreamSynchronize(r->stream));
+    return 0;
+}
+
+int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
+    RDR_CHECK(r && scene, "rdr_set_scene: null argument");
+    RDR_HIP(hipSetDevice(r->device));
+    RDR_HIP(hipStreamSynchronize(r->stream));
+    const rdr_scene_desc& s = *scene;
+    if (validate_scene(s)) return 1;
+    r->has_scene = false;
+
+    if (r->vertices.upload(s.vertices, s.vertex_count)) return 1;
+    {
+        // positions as three planes so the rasteriser's per-vertex gathers touch 12 useful bytes
+        std::vector<float> px(s.vertex_count), py(s.vertex_count), pz(s.vertex_count);
+        for (uint32_t i = 0; i < s.vertex_count; ++i) {
+            px[i] = s.vertices[i].p[0]; py[i] = s.vertices[i].p[1]; pz[i] = s.vertices[i].p[2];
+        }
+        if (r->pos_x.upload(px.data(), px.size()) || r->pos_y.upload(py.data(), py.size()) || r->pos_z.upload(pz.data(), pz.size())) return 1;
+    }
+    if (r->meshlet_vertices.upload(s.meshlet_vertices, s.meshlet_vertex_count)) return 1;
+    {
+        // a few bytes of slack: triangle indices are fetched with byte loads only, but keep the tail mapped
+        std::vector<uint8_t> tri(s.meshlet_triangle_bytes + 16, 0);
+        if (s.meshlet_triangle_bytes) std::memcpy(tri.data(), s.meshlet_triangles, s.meshlet_triangle_bytes);
+        if (r->meshlet_triangles.upload(tri.data(), tri.size())) return 1;
+    }
+    if (r->meshlets.upload(s.meshlets, s.meshlet_count)) return 1;
+    if (r->meshes.upload(s.meshes, s.mesh_count)) return 1;
+    if (r->draws.upload(s.mesh_draws, s.draw_count)) return 1;
+    if (r->materials.upload(s.materials, s.material_count)) return 1;
+    if (r->transforms.upload(s.global_transforms, (size_t)s.transform_count * 16)) return 1;
+    if (r->draw_lod.alloc(s.draw_count)) return 1;
+    RDR_HIP(hipMemset(r->draw_lod.ptr, 0xFF, std::max<size_t>(s.draw_count, 1)));
+
+    // meshlet instance -> draw, and work-list capacities
+    uint64_t cmd_cap = 0, vis_cap = 0, tri_total = 0;
+    {
+        std::vector<uint32_t> inst(std::max<uint32_t>(s.meshlet_visibility_count, 1), 0u);
+        for (uint32_t di = 0; di < s.draw_count; ++di) {
+            const rdr_mesh_draw& d = s.mesh_draws[di];
+            const rdr_mesh& m = s.meshes[d.mesh_index];
+            const uint32_t n0 = m.lods[0].meshlet_count;
+            for (uint32_t k = 0; k < n0; ++k) inst[d.meshlet_visibility_offset + k] = di;
+            cmd_cap += (n0 + 63) / 64;
+            vis_cap += n0;
+            tri_total += (uint64_t)n0 * 124;
+        }
+        if (r->instance_draw.upload(inst.data(), inst.size())) return 1;
+    }
+    if (r->commands.alloc(cmd_cap) || r->visible.alloc(vis_cap)) return 1;
+    if (r->deferred.alloc((size_t)std::min<uint64_t>(std::max<uint64_t>(tri_total, 1u << 16), 1u << 20))) return 1;
+
+    // textures and environment
+    {
+        TexelPacker tp;
+        std::vector<GpuImage> imgs(s.image_count);
+        for (uint32_t i = 0; i < s.image_count; ++i) imgs[i] = pack_image(tp, s.images[i]);
+        static const float zero_lut[4] = {0, 0, 0, 0};
+        rdr_image_desc lut_desc{zero_lut, 1, 1, 1, RDR_FORMAT_RGBA32F};
+        if (s.env && s.env->brdf_lut.data) {
+            lut_desc = s.env->brdf_lut;
+            RDR_CHECK(lut_desc.width && lut_desc.height && lut_desc.mip_count >= 1 && lut_desc.mip_count <= 17 && lut_desc.format <= RDR_FORMAT_RGBA32F,
+                      "scene: brdf_lut invalid");
+        }
+        r->sv.brdf_lut = pack_image(tp, lut_desc);
+        if (pack_cubemap(tp, s.env ? &s.env->lambertian : nullptr, &r->sv.lambertian)) return 1;
+        if (pack_cubemap(tp, s.env ? &s.env->ggx : nullptr, &r->sv.ggx)) return 1;
+        if (pack_cubemap(tp, s.env ? &s.env->charlie : nullptr, &r->sv.charlie)) return 1;
+        if (r->images.upload(imgs.data(), imgs.size())) return 1;
+        if (r->texels.upload(tp.blob.data(), tp.blob.size())) return 1;
+    }
+
+    // shadow-ray structure
+    rdr_build_blas(s, r->bvh);
+    rdr_build_tlas(s, s.global_transforms, r->bvh);
+    if (r->blas.upload(r->bvh.blas_nodes.data(), r->bvh.blas_nodes.size())) return 1;
+    if (r->blas_tris.upload(r->bvh.blas_tris.data(), r->bvh.blas_tris.size())) return 1;
+    r->h_draws.assign(s.mesh_draws, s.mesh_draws + s.draw_count);
+    r->h_meshes.assign(s.meshes, s.meshes + s.mesh_count);
+
+    SceneView& sv = r->sv;
+    sv.vertices = r->vertices.ptr;
+    sv.pos_x = r->pos_x.ptr; sv.pos_y = r->pos_y.ptr; sv.pos_z = r->pos_z.ptr;
+    sv.meshlet_vertices = r->meshlet_vertices.ptr;
+    sv.meshlet_triangles = r->meshlet_triangles.ptr;
+    sv.meshlets = r->meshlets.ptr;
+    sv.meshes = r->meshes.ptr;
+    sv.draws = r->draws.ptr;
+    sv.materials = r->materials.ptr;
+    sv.transforms = r->transforms.ptr;
+    sv.instance_draw = r->instance_draw.ptr;
+    sv.draw_lod = r->draw_lod.ptr;
+    sv.images = r->images.ptr;
+    sv.texels = r->texels.ptr;
+    sv.srgb_lut = r->srgb_lut.ptr;
+    sv.draw_count = s.draw_count;
+    sv.material_count = s.material_count;
+    sv.image_count = s.image_count;
+    sv.meshlet_count = s.meshlet_count;
+    sv.blas = r->blas.ptr;
+    sv.blas_tris = r->blas_tris.ptr;
+    if (upload_tlas(r)) return 1;
+    r->meshlet_visibility_count = s.meshlet_visibility_count;
+    RDR_HIP(hipDeviceSynchronize());
+    r->has_scene = true;
+    r->frame_rendered = false;
+    return 0;
+}
+
+int rdr_update_transforms(rdr_renderer* r, const float* mat4s, uint32_t count) {
+    RDR_CHECK(r && mat4s, "rdr_update_transforms: null argument");
+    RDR_CHECK(r->has_scene, "rdr_update_transforms: no scene set");
+    RDR_CHECK((size_t)count * 16 == r->transforms.count, "rdr_update_transforms: the whole transform array must be passed");
+    RDR_HIP(hipSetDevice(r->device));
+    RDR_HIP(hipStreamSynchronize(r->stream));
+    RDR_HIP(hipMemcpy(r->transforms.ptr, mat4s, (size_t)count * 64, hipMemcpyHostToDevice));
+    // the shadow ray sees the moved instances: rebuild the top level
+    rdr_scene_desc s{};
+    s.mesh_draws = r->h_draws.data();
+    s.draw_count = (uint32_t)r->h_draws.size();
+    s.meshes = r->h_meshes.data();
+    s.mesh_count = (uint32_t)r->h_meshes.size();
+    rdr_build_tlas(s, mat4s, r->bvh);
+    if (upload_tlas(r)) return 1;
+    RDR_HIP(hipDeviceSynchronize()); // the reference waits for device idle here (renderer.rs:718)
+    return 0;
+}
+
+int rdr_set_partition(rdr_renderer* r, uint32_t instance_lo, uint32_t instance_hi) {
+    RDR_CHECK(r, "rdr_set_partition: renderer is null");
+    RDR_CHECK(instance_lo <= instance_hi, "rdr_set_partition: lo > hi");
+    r->part_lo = instance_lo; r->part_hi = instance_hi;
+    return 0;
+}
+
+int rdr_set_shade_rows(rdr_renderer* r, uint32_t row_lo, uint32_t row_hi) {
+    RDR_CHECK(r, "rdr_set_shade_rows: renderer is null");
+    RDR_CHECK(row_lo <= row_hi, "rdr_set_shade_rows: lo > hi");
+    r->row_lo = row_lo; r->row_hi = row_hi;
+    return 0;
+}
+
+int rdr_render_visbuffer(rdr_renderer* r, const float cam_pos[3], const float cam_dir[3], const float sun_dir[3]) {
+    RDR_CHECK(r && cam_pos && cam_dir && sun_dir, "rdr_render_visbuffer: null argument");
+    RDR_CHECK(r->has_scene, "rdr_render_visbuffer: no scene set");
+    RDR_HIP(hipSetDevice(r->device));
+    build_ubo(r->width, r->height, cam_pos, cam_dir, sun_dir, r->sv.draw_count, r->cfg.lod_enabled, r->cfg.cull_enabled, &r->ubo);
+    const FrameView fv = make_frame_view(r);
+    if (rdr_launch_geometry(r->sv, fv, r->stream, r->cfg.time_kernels ? r->events : nullptr)) return 1;
+    r->frame_rendered = true;
+    return 0;
+}
+
+int rdr_shade(rdr_renderer* r) {
+    RDR_CHECK(r, "rdr_shade: renderer is null");
+    RDR_CHECK(r->has_scene && r->frame_rendered, "rdr_shade: no visibility buffer rendered yet");
+    RDR_HIP(hipSetDevice(r->device));
+    const FrameView fv = make_frame_view(r);
+    if (r->cfg.time_kernels) RDR_HIP(hipEventRecord(r->events[6], r->stream));
+    if (rdr_launch_shade(r->sv, fv, r->stream)) return 1;
+    if (r->cfg.time_kernels) RDR_HIP(hipEventRecord(r->events[7], r->stream));
+    return 0;
+}
+
+int rdr_render(rdr_renderer* r, const float cam_pos[3], const float cam_dir[3], const float sun_dir[3]) {
+    if (rdr_render_visbuffer(r, cam_pos, cam_dir, sun_dir)) return 1;
+    return rdr_shade(r);
+}
+
+void* rdr_visbuffer_device_ptr(rdr_renderer* r) { return r ? r->vis.ptr : nullptr; }
+void* rdr_color_device_ptr(rdr_renderer* r) { return r ? r->color.ptr : nullptr; }
+
+int rdr_read_visbuffer_u64(rdr_renderer* r, uint64_t* out) {
+    RDR_CHECK(r && out, "rdr_read_visbuffer_u64: null argument");
+    RDR_CHECK(r->frame_rendered, "rdr_read_visbuffer_u64: nothing rendered yet");
+    RDR_HIP(hipSetDevice(r->device));
+    FrameCounters fc;
+    if (fetch_counters(r, &fc)) return 1;
+    RDR_HIP(hipMemcpy(out, r->vis.ptr, (size_t)r->width * r->height * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int rdr_read_visbuffer(rdr_renderer* r, uint32_t* out_xy) {
+    RDR_CHECK(r && out_xy, "rdr_read_visbuffer: null argument");
+    RDR_CHECK(r->frame_rendered, "rdr_read_visbuffer: nothing rendered yet");
+    RDR_HIP(hipSetDevice(r->device));
+    FrameCounters fc;
+    if (fetch_counters(r, &fc)) return 1;
+    const size_t npx = (size_t)r->width * r->height;
+    if (r->resolve_out.count != npx * 2 && r->resolve_out.alloc(npx * 2)) return 1;
+    const FrameView fv = make_frame_view(r);
+    if (rdr_launch_resolve(r->sv, fv, r->resolve_out.ptr, r->stream)) return 1;
+    RDR_HIP(hipStreamSynchronize(r->stream));
+    RDR_HIP(hipMemcpy(out_xy, r->resolve_out.ptr, npx * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int rdr_read_color(rdr_renderer* r, uint8_t* out) {
+    RDR_CHECK(r && out, "rdr_read_color: null argument");
+    RDR_CHECK(r->frame_rendered, "rdr_read_color: nothing rendered yet");
+    RDR_HIP(hipSetDevice(r->device));
+    FrameCounters fc;
+    if (fetch_counters(r, &fc)) return 1;
+    RDR_HIP(hipMemcpy(out, r->color.ptr, (size_t)r->width * r->height * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int rdr_get_stats(rdr_renderer* r, rdr_stats* out) {
+    RDR_CHECK(r && out, "rdr_get_stats: null argument");
+    RDR_HIP(hipSetDevice(r->device));
+    FrameCounters fc;
+    if (fetch_counters(r, &fc)) return 1;
+    rdr_stats st{};
+    st.draws_visible = fc.draws_visible;
+    st.commands = fc.cmd_count;
+    st.meshlets_tested = fc.meshlets_tested;
+    st.meshlets_visible = fc.meshlets_visible;
+    st.triangles_submitted = fc.triangles_submitted;
+    st.triangles_tested = fc.triangles_tested;
+    st.triangles_rasterised = fc.triangles_rasterised;
+    st.triangles_big = fc.triangles_big;
+    st.fragments = fc.fragments;
+    st.pixels_covered = fc.pixels_covered;
+    if (r->cfg.time_kernels && r->frame_rendered) {
+        // events 0..5 bracket clear, draw cull, meshlet cull, raster, deferred; 6..7 bracket shading
+        const int map[5] = {RDR_K_CLEAR, RDR_K_DRAW_CULL, RDR_K_MESHLET_CULL, RDR_K_RASTER, RDR_K_BIG_RASTER};
+        for (int i = 0; i < 5; ++i) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, r->events[i], r->events[i + 1]) == hipSuccess) st.kernel_ms[map[i]] = ms;
+        }
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, r->events[6], r->events[7]) == hipSuccess) st.kernel_ms[RDR_K_SHADE] = ms;
+        (void)hipGetLastError();
+    }
+    *out = st;
+    return 0;
+}
+
+int rdr_get_ubo(rdr_renderer* r, rdr_ubo* out) {
+    RDR_CHECK(r && out, "rdr_get_ubo: null argument");
+    *out = r->ubo;
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,260 @@
+// rdr_bvh.cpp — host-side build of the shadow-ray acceleration structure.
+//
+// Stands in for the Vulkan BLAS/TLAS the reference builds at scene load
+// (renderer/src/renderer/acceleration_sturct_utils.rs:15-49: one BLAS per mesh
+// over its LOD0 index list; :253-310: one TLAS instance per draw carrying the
+// draw's model matrix; everything flagged opaque).  Two-level binary BVH with
+// binned-SAH splits; leaves hold up to four triangles stored as bare positions
+// in leaf order so the traversal kernel reads them contiguously.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "rdr_internal.h"
+
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::numeric_limits<float>::infinity();
+            hi[k] = -std::numeric_limits<float>::infinity();
+        }
+    }
+    void grow(const float* p) {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(lo[k], p[k]);
+            hi[k] = std::max(hi[k], p[k]);
+        }
+    }
+    void grow(const Box& b) {
+        grow(b.lo);
+        grow(b.hi);
+    }
+    float half_area() const {
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (!(dx >= 0.0f)) return 0.0f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Item {
+    Box box;
+    float c[3];
+    uint32_t index;
+};
+
+constexpr int kBins = 12;
+constexpr int kLeafSize = 4;
+
+// Recursive binned-SAH build over items[first, first+count). Node indices are
+// relative to `nodes` (the caller offsets them), children adjacent.
+void build_rec(std::vector<BvhNode>& nodes, std::vector<Item>& items, uint32_t node, uint32_t first, uint32_t count,
+               int depth) {
+    Box bounds, cbounds;
+    bounds.reset();
+    cbounds.reset();
+    for (uint32_t i = 0; i < count; ++i) {
+        bounds.grow(items[first + i].box);
+        cbounds.grow(items[first + i].c);
+    }
+    for (int k = 0; k < 3; ++k) {
+        nodes[node].lo[k] = bounds.lo[k];
+        nodes[node].hi[k] = bounds.hi[k];
+    }
+    auto make_leaf = [&]() {
+        nodes[node].left = (int32_t)first;
+        nodes[node].count = (int32_t)count;
+    };
+    if (count <= (uint32_t)kLeafSize || depth > 40) {
+        // depth guard: never deeper than the traversal stack allows
+        if (count <= 255) { make_leaf(); return; }
+    }
+    int axis = 0;
+    float ext = cbounds.hi[0] - cbounds.lo[0];
+    for (int k = 1; k < 3; ++k)
+        if (cbounds.hi[k] - cbounds.lo[k] > ext) { ext = cbounds.hi[k] - cbounds.lo[k]; axis = k; }
+    uint32_t mid = count / 2;
+    bool split_done = false;
+    if (ext > 0.0f && count > 8) {
+        Box bin_box[kBins];
+        uint32_t bin_n[kBins] = {0};
+        for (auto& b : bin_box) b.reset();
+        const float scale = (float)kBins / ext;
+        for (uint32_t i = 0; i < count; ++i) {
+            int b = (int)((items[first + i].c[axis] - cbounds.lo[axis]) * scale);
+            b = std::min(std::max(b, 0), kBins - 1);
+            bin_n[b]++;
+            bin_box[b].grow(items[first + i].box);
+        }
+        float right_area[kBins];
+        uint32_t right_n[kBins];
+        Box acc;
+        acc.reset();
+        uint32_t n = 0;
+        for (int b = kBins - 1; b > 0; --b) {
+            if (bin_n[b]) acc.grow(bin_box[b]);
+            n += bin_n[b];
+            right_area[b] = acc.half_area();
+            right_n[b] = n;
+        }
+        acc.reset();
+        n = 0;
+        float best = std::numeric_limits<float>::infinity();
+        int best_b = -1;
+        for (int b = 0; b < kBins - 1; ++b) {
+            if (bin_n[b]) acc.grow(bin_box[b]);
+            n += bin_n[b];
+            if (n == 0 || right_n[b + 1] == 0) continue;
+            const float cost = acc.half_area() * (float)n + right_area[b + 1] * (float)right_n[b + 1];
+            if (cost < best) { best = cost; best_b = b; }
+        }
+        if (best_b >= 0) {
+            const float lo = cbounds.lo[axis];
+            auto it = std::partition(items.begin() + first, items.begin() + first + count, [&](const Item& it_) {
+                int b = (int)((it_.c[axis] - lo) * scale);
+                b = std::min(std::max(b, 0), kBins - 1);
+                return b <= best_b;
+            });
+            mid = (uint32_t)(it - (items.begin() + first));
+            split_done = mid > 0 && mid < count;
+        }
+    }
+    if (!split_done) {
+        mid = count / 2;
+        std::nth_element(items.begin() + first, items.begin() + first + mid, items.begin() + first + count,
+                         [axis](const Item& a, const Item& b) { return a.c[axis] < b.c[axis]; });
+    }
+    const uint32_t l = (uint32_t)nodes.size();
+    nodes.emplace_back();
+    nodes.emplace_back();
+    nodes[node].left = (int32_t)l;
+    nodes[node].count = 0;
+    build_rec(nodes, items, l, first, mid, depth + 1);
+    build_rec(nodes, items, l + 1, first + mid, count - mid, depth + 1);
+}
+
+void build(std::vector<BvhNode>& nodes, std::vector<Item>& items) {
+    nodes.clear();
+    nodes.emplace_back();
+    if (items.empty()) {
+        BvhNode& r = nodes[0];
+        for (int k = 0; k < 3; ++k) { r.lo[k] = 1.0f; r.hi[k] = -1.0f; } // never hit
+        r.left = 0;
+        r.count = 0;
+        return;
+    }
+    build_rec(nodes, items, 0, 0, (uint32_t)items.size(), 0);
+}
+
+uint32_t mesh_index_count(const rdr_scene_desc& s, uint32_t mi) {
+    const uint32_t end = mi + 1 < s.mesh_count ? s.meshes[mi + 1].index_offset : s.index_count;
+    return end - s.meshes[mi].index_offset;
+}
+
+// Inverse of the affine part of a column-major mat4: adjugate over determinant
+// in double precision, every element rounded to float once.
+void affine_inverse(const float* m, float* out12) {
+    const double a00 = m[0], a10 = m[1], a20 = m[2];
+    const double a01 = m[4], a11 = m[5], a21 = m[6];
+    const double a02 = m[8], a12 = m[9], a22 = m[10];
+    const double tx = m[12], ty = m[13], tz = m[14];
+    const double c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+    const double det = a00 * c00 + a01 * c01 + a02 * c02;
+    const double id = 1.0 / det;
+    const double i00 = c00 * id, i01 = (a02 * a21 - a01 * a22) * id, i02 = (a01 * a12 - a02 * a11) * id;
+    const double i10 = c01 * id, i11 = (a00 * a22 - a02 * a20) * id, i12 = (a02 * a10 - a00 * a12) * id;
+    const double i20 = c02 * id, i21 = (a01 * a20 - a00 * a21) * id, i22 = (a00 * a11 - a01 * a10) * id;
+    out12[0] = (float)i00; out12[1] = (float)i01; out12[2] = (float)i02;
+    out12[3] = (float)(-(i00 * tx + i01 * ty + i02 * tz));
+    out12[4] = (float)i10; out12[5] = (float)i11; out12[6] = (float)i12;
+    out12[7] = (float)(-(i10 * tx + i11 * ty + i12 * tz));
+    out12[8] = (float)i20; out12[9] = (float)i21; out12[10] = (float)i22;
+    out12[11] = (float)(-(i20 * tx + i21 * ty + i22 * tz));
+}
+
+} // namespace
+
+void rdr_build_blas(const rdr_scene_desc& s, HostBvh& out) {
+    out.blas_nodes.clear();
+    out.blas_tris.clear();
+    out.mesh_root.assign(s.mesh_count, 0);
+    out.mesh_tri_base.assign(s.mesh_count, 0);
+    std::vector<BvhNode> nodes;
+    std::vector<Item> items;
+    for (uint32_t mi = 0; mi < s.mesh_count; ++mi) {
+        const rdr_mesh& mesh = s.meshes[mi];
+        const uint32_t ntri = mesh_index_count(s, mi) / 3;
+        items.resize(ntri);
+        for (uint32_t t = 0; t < ntri; ++t) {
+            Item& it = items[t];
+            it.box.reset();
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t vi = s.indices[mesh.index_offset + 3 * t + k] + mesh.vertex_offset;
+                it.box.grow(s.vertices[vi].p);
+            }
+            for (int k = 0; k < 3; ++k) {
+                // keep flat triangles from producing zero-thickness slabs
+                const float pad = 2e-6f * std::max(std::fabs(it.box.lo[k]), std::fabs(it.box.hi[k])) + 1e-30f;
+                it.box.lo[k] -= pad;
+                it.box.hi[k] += pad;
+                it.c[k] = 0.5f * (it.box.lo[k] + it.box.hi[k]);
+            }
+            it.index = t;
+        }
+        build(nodes, items);
+        out.mesh_root[mi] = (uint32_t)out.blas_nodes.size();
+        out.mesh_tri_base[mi] = (uint32_t)(out.blas_tris.size() / 9);
+        out.blas_nodes.insert(out.blas_nodes.end(), nodes.begin(), nodes.end());
+        for (uint32_t t = 0; t < ntri; ++t) {
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t vi = s.indices[mesh.index_offset + 3 * items[t].index + k] + mesh.vertex_offset;
+                out.blas_tris.push_back(s.vertices[vi].p[0]);
+                out.blas_tris.push_back(s.vertices[vi].p[1]);
+                out.blas_tris.push_back(s.vertices[vi].p[2]);
+            }
+        }
+    }
+}
+
+void rdr_build_tlas(const rdr_scene_desc& s, const float* transforms, HostBvh& io) {
+    std::vector<Item> items(s.draw_count);
+    io.instances.resize(s.draw_count);
+    for (uint32_t di = 0; di < s.draw_count; ++di) {
+        const rdr_mesh_draw& d = s.mesh_draws[di];
+        const float* m = transforms + (size_t)d.model_index * 16;
+        GpuInstance& inst = io.instances[di];
+        affine_inverse(m, inst.inv);
+        inst.blas_root = io.mesh_root[d.mesh_index];
+        inst.tri_base = io.mesh_tri_base[d.mesh_index];
+        inst._pad[0] = inst._pad[1] = 0;
+        const BvhNode& root = io.blas_nodes[inst.blas_root];
+        Item& it = items[di];
+        it.box.reset();
+        it.index = di;
+        if (root.lo[0] <= root.hi[0]) {
+            for (int corner = 0; corner < 8; ++corner) {
+                const float x = (corner & 1) ? root.hi[0] : root.lo[0];
+                const float y = (corner & 2) ? root.hi[1] : root.lo[1];
+                const float z = (corner & 4) ? root.hi[2] : root.lo[2];
+                const float w[3] = {m[0] * x + m[4] * y + m[8] * z + m[12], m[1] * x + m[5] * y + m[9] * z + m[13],
+                                    m[2] * x + m[6] * y + m[10] * z + m[14]};
+                it.box.grow(w);
+            }
+            for (int k = 0; k < 3; ++k) {
+                const float pad = 1e-4f * (it.box.hi[k] - it.box.lo[k]) + 1e-6f * (1.0f + std::fabs(it.box.hi[k]) + std::fabs(it.box.lo[k]));
+                it.box.lo[k] -= pad;
+                it.box.hi[k] += pad;
+            }
+        } else {
+            const float far_away[3] = {3e38f, 3e38f, 3e38f};
+            it.box.grow(far_away);
+        }
+        for (int k = 0; k < 3; ++k) it.c[k] = 0.5f * (it.box.lo[k] + it.box.hi[k]);
+    }
+    build(io.tlas_nodes, items);
+    io.tlas_items.resize(items.size());
+    for (size_t i = 0; i < items.size(); ++i) io.tlas_items[i] = items[i].index;
+}

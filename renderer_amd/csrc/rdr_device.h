@@ -1,0 +1,249 @@
+// rdr_device.h — device-side math and the software texture sampler.
+//
+// Numeric contract of every kernel that decides which triangle owns a pixel:
+// IEEE binary32, no fused multiply-add except where fmaf is spelled out, sums
+// left to right, correctly rounded division and square root.  The library is
+// compiled with -ffp-contract=off so that the expressions below mean exactly
+// what they say.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rdr_internal.h"
+
+#define RDR_DEV __device__ __forceinline__
+
+struct vec3 {
+    float x, y, z;
+};
+struct vec4 {
+    float x, y, z, w;
+};
+
+RDR_DEV vec3 mk3(float x, float y, float z) { return vec3{x, y, z}; }
+RDR_DEV vec4 mk4(float x, float y, float z, float w) { return vec4{x, y, z, w}; }
+RDR_DEV vec3 operator+(vec3 a, vec3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RDR_DEV vec3 operator-(vec3 a, vec3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RDR_DEV vec3 operator*(vec3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+RDR_DEV vec3 operator*(vec3 a, vec3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RDR_DEV float dot3(vec3 a, vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+RDR_DEV float len3(vec3 a) { return sqrtf(dot3(a, a)); }
+RDR_DEV vec3 cross3(vec3 a, vec3 b) {
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// GLSL normalize(): divide by the length; 0/0 stays NaN.
+RDR_DEV vec3 normalize3(vec3 a) {
+    float l = len3(a);
+    return mk3(a.x / l, a.y / l, a.z / l);
+}
+RDR_DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+RDR_DEV float max3f(float a, float b, float c) { return fmaxf(a, fmaxf(b, c)); }
+
+// Column-major mat4 * vec4: ((c0*x + c1*y) + c2*z) + c3*w per row.
+RDR_DEV vec4 mul_m4(const float* m, vec4 v) {
+    vec4 r;
+    r.x = ((m[0] * v.x + m[4] * v.y) + m[8] * v.z) + m[12] * v.w;
+    r.y = ((m[1] * v.x + m[5] * v.y) + m[9] * v.z) + m[13] * v.w;
+    r.z = ((m[2] * v.x + m[6] * v.y) + m[10] * v.z) + m[14] * v.w;
+    r.w = ((m[3] * v.x + m[7] * v.y) + m[11] * v.z) + m[15] * v.w;
+    return r;
+}
+// mat3(m) * v
+RDR_DEV vec3 mul_m3(const float* m, vec3 v) {
+    return mk3((m[0] * v.x + m[4] * v.y) + m[8] * v.z, (m[1] * v.x + m[5] * v.y) + m[9] * v.z,
+               (m[2] * v.x + m[6] * v.y) + m[10] * v.z);
+}
+
+// Load a 4x4 matrix whose address is the same in every lane of the wave.
+RDR_DEV void load_m4(const float* p, float* m) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = p[i];
+}
+
+RDR_DEV float model_max_scale(const float* m) {
+    float sx = len3(mk3(m[0], m[1], m[2]));
+    float sy = len3(mk3(m[4], m[5], m[6]));
+    float sz = len3(mk3(m[8], m[9], m[10]));
+    return fmaxf(sx, fmaxf(sy, sz));
+}
+
+// ---- wave64 helpers ----------------------------------------------------------
+RDR_DEV uint32_t lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+// Number of set bits of a wave ballot below this lane.
+RDR_DEV uint32_t ballot_rank(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+RDR_DEV uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+RDR_DEV unsigned long long wave_sum64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// Inclusive prefix sum across the wave.
+RDR_DEV uint32_t wave_scan_inclusive(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o, 64);
+        if (lane >= (uint32_t)o) v += t;
+    }
+    return v;
+}
+
+// ---- texture sampler -----------------------------------------------------------
+// One sampler for every texture: LINEAR mag/min/mip, REPEAT, LOD 0..16
+// (reference: renderer/src/renderer.rs:755-763).
+
+RDR_DEV uint32_t mip_dim(uint32_t d, uint32_t level) {
+    uint32_t v = d >> level;
+    return v ? v : 1u;
+}
+
+RDR_DEV vec4 decode_texel(const uint8_t* p, uint32_t format, const float* srgb_lut) {
+    if (format == RDR_FORMAT_RGBA32F) {
+        const float4 f = *reinterpret_cast<const float4*>(p);
+        return mk4(f.x, f.y, f.z, f.w);
+    }
+    const uint32_t t = *reinterpret_cast<const uint32_t*>(p);
+    const uint32_t r = t & 255u, g = (t >> 8) & 255u, b = (t >> 16) & 255u, a = t >> 24;
+    if (format == RDR_FORMAT_RGBA8_SRGB)
+        return mk4(srgb_lut[r], srgb_lut[g], srgb_lut[b], (float)a / 255.0f);
+    return mk4((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f, (float)a / 255.0f);
+}
+
+RDR_DEV vec4 lerp4(vec4 a, vec4 b, float t) {
+    const float s = 1.0f - t;
+    return mk4(a.x * s + b.x * t, a.y * s + b.y * t, a.z * s + b.z * t, a.w * s + b.w * t);
+}
+
+RDR_DEV int wrap_repeat(int i, int n) {
+    int m = i % n;
+    return m < 0 ? m + n : m;
+}
+
+RDR_DEV vec4 image_bilinear(const GpuImage& im, const uint8_t* texels, const float* lut, uint32_t level,
+                            float u, float v) {
+    const int w = (int)mip_dim(im.width, level), h = (int)mip_dim(im.height, level);
+    const uint32_t tb = im.format == RDR_FORMAT_RGBA32F ? 16u : 4u;
+    const uint8_t* base = texels + im.offset + im.level_offset[level];
+    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    const float ax = x - fx, ay = y - fy;
+    const int x0 = wrap_repeat((int)fx, w), x1 = wrap_repeat((int)fx + 1, w);
+    const int y0 = wrap_repeat((int)fy, h), y1 = wrap_repeat((int)fy + 1, h);
+    const vec4 t00 = decode_texel(base + ((size_t)y0 * w + x0) * tb, im.format, lut);
+    const vec4 t10 = decode_texel(base + ((size_t)y0 * w + x1) * tb, im.format, lut);
+    const vec4 t01 = decode_texel(base + ((size_t)y1 * w + x0) * tb, im.format, lut);
+    const vec4 t11 = decode_texel(base + ((size_t)y1 * w + x1) * tb, im.format, lut);
+    return lerp4(lerp4(t00, t10, ax), lerp4(t01, t11, ax), ay);
+}
+
+RDR_DEV vec4 image_sample_lod(const GpuImage& im, const uint8_t* texels, const float* lut, float u, float v,
+                              float lod) {
+    float maxl = (float)(im.mip_count - 1);
+    if (maxl > 16.0f) maxl = 16.0f;
+    if (!(lod > 0.0f)) lod = 0.0f;
+    if (lod > maxl) lod = maxl;
+    const float fl = floorf(lod);
+    const uint32_t l0 = (uint32_t)fl;
+    const uint32_t l1 = l0 + 1 < im.mip_count ? l0 + 1 : l0;
+    const float t = lod - fl;
+    const vec4 a = image_bilinear(im, texels, lut, l0, u, v);
+    if (l1 == l0 || t == 0.0f) return a;
+    const vec4 b = image_bilinear(im, texels, lut, l1, u, v);
+    return lerp4(a, b, t);
+}
+
+RDR_DEV vec4 image_sample_grad(const GpuImage& im, const uint8_t* texels, const float* lut, float u, float v,
+                               float dudx, float dvdx, float dudy, float dvdy) {
+    const float w = (float)im.width, h = (float)im.height;
+    const float ax = dudx * w, ay = dvdx * h, bx = dudy * w, by = dvdy * h;
+    const float rx = sqrtf(ax * ax + ay * ay), ry = sqrtf(bx * bx + by * by);
+    const float rho = fmaxf(rx, ry);
+    return image_sample_lod(im, texels, lut, u, v, log2f(rho));
+}
+
+// ---- cubemaps ------------------------------------------------------------------
+RDR_DEV int cube_face(vec3 d, float& sc, float& tc, float& ma) {
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    if (ax >= ay && ax >= az) {
+        ma = ax;
+        if (d.x >= 0.0f) { sc = -d.z; tc = -d.y; return 0; }
+        sc = d.z; tc = -d.y; return 1;
+    }
+    if (ay >= az) {
+        ma = ay;
+        if (d.y >= 0.0f) { sc = d.x; tc = d.z; return 2; }
+        sc = d.x; tc = -d.z; return 3;
+    }
+    ma = az;
+    if (d.z >= 0.0f) { sc = d.x; tc = -d.y; return 4; }
+    sc = -d.x; tc = -d.y; return 5;
+}
+
+RDR_DEV vec3 cube_dir(int face, float a, float b) {
+    switch (face) {
+    case 0: return mk3(1.0f, -b, -a);
+    case 1: return mk3(-1.0f, -b, a);
+    case 2: return mk3(a, 1.0f, b);
+    case 3: return mk3(a, -1.0f, -b);
+    case 4: return mk3(a, -b, 1.0f);
+    default: return mk3(-a, -b, -1.0f);
+    }
+}
+
+RDR_DEV vec4 cube_fetch(const GpuCubemap& cm, const uint8_t* texels, uint32_t level, int face, int i, int j) {
+    const int n = (int)mip_dim(cm.size, level);
+    const uint32_t tb = cm.format == RDR_FORMAT_RGBA32F ? 16u : 4u;
+    if (i < 0 || j < 0 || i >= n || j >= n) {
+        // seamless edge: re-project the out-of-face texel centre onto the cube
+        const float a = ((float)i + 0.5f) / (float)n * 2.0f - 1.0f;
+        const float b = ((float)j + 0.5f) / (float)n * 2.0f - 1.0f;
+        const vec3 d = cube_dir(face, a, b);
+        float sc, tc, ma;
+        face = cube_face(d, sc, tc, ma);
+        const float s = 0.5f * (sc / ma + 1.0f), t = 0.5f * (tc / ma + 1.0f);
+        i = (int)floorf(s * (float)n);
+        j = (int)floorf(t * (float)n);
+        i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+        j = j < 0 ? 0 : (j > n - 1 ? n - 1 : j);
+    }
+    const uint8_t* base = texels + cm.offset + cm.level_offset[level] + (size_t)face * n * n * tb;
+    return decode_texel(base + ((size_t)j * n + i) * tb, cm.format, nullptr);
+}
+
+RDR_DEV vec4 cube_bilinear(const GpuCubemap& cm, const uint8_t* texels, uint32_t level, vec3 d) {
+    float sc, tc, ma;
+    const int face = cube_face(d, sc, tc, ma);
+    const int n = (int)mip_dim(cm.size, level);
+    const float s = 0.5f * (sc / ma + 1.0f), t = 0.5f * (tc / ma + 1.0f);
+    const float x = s * (float)n - 0.5f, y = t * (float)n - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    const float ax = x - fx, ay = y - fy;
+    const int i0 = (int)fx, j0 = (int)fy;
+    const vec4 t00 = cube_fetch(cm, texels, level, face, i0, j0);
+    const vec4 t10 = cube_fetch(cm, texels, level, face, i0 + 1, j0);
+    const vec4 t01 = cube_fetch(cm, texels, level, face, i0, j0 + 1);
+    const vec4 t11 = cube_fetch(cm, texels, level, face, i0 + 1, j0 + 1);
+    return lerp4(lerp4(t00, t10, ax), lerp4(t01, t11, ax), ay);
+}
+
+RDR_DEV vec4 cube_sample_lod(const GpuCubemap& cm, const uint8_t* texels, vec3 d, float lod) {
+    const float maxl = (float)(cm.mip_count - 1);
+    if (!(lod > 0.0f)) lod = 0.0f;
+    if (lod > maxl) lod = maxl;
+    const float fl = floorf(lod);
+    const uint32_t l0 = (uint32_t)fl;
+    const uint32_t l1 = l0 + 1 < cm.mip_count ? l0 + 1 : l0;
+    const float t = lod - fl;
+    const vec4 a = cube_bilinear(cm, texels, l0, d);
+    if (l1 == l0 || t == 0.0f) return a;
+    const vec4 b = cube_bilinear(cm, texels, l1, d);
+    return lerp4(a, b, t);
+}

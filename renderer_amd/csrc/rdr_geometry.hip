@@ -1,0 +1,705 @@
+// rdr_geometry.hip — cull -> vertex transform -> rasterise into the 64-bit
+// depth|ID visibility buffer.
+//
+// What the kernels compute follows the reference's shaders (paths relative to
+// the reference tree):
+//   k_draw_cull      assets/shaders/cull.comp.glsl:54-130
+//   k_meshlet_cull   assets/shaders/shader.task.glsl:59-137
+//   k_raster         assets/shaders/shader.mesh.glsl:72-131 + the fixed-function
+//                    state of lava/src/pipelines.rs:149-191 + the alpha test of
+//                    assets/shaders/shader.frag.glsl:55-69
+// How they compute it is specific to CDNA4: wave64 ballot/prefix compaction in
+// place of per-item global atomics, persistent grids reading work-list lengths
+// from memory in place of indirect dispatch, one wave per meshlet with the 64
+// transformed vertices in LDS, and a 64-bit atomic min per covered sample in
+// place of ROPs + a depth buffer.
+//
+// The reference's early/late occlusion split is a conservative optimisation
+// that does not change the image; one pass over every draw is run.
+#include "rdr_device.h"
+
+namespace {
+
+constexpr float kGuardBand = 8.0f;
+constexpr int kSmallExtent = 64 * 256;  // bounding boxes up to 64 px are scanned by one lane in int32
+constexpr int kLaneMaxPixels = 256;     // larger boxes go to the wave-cooperative path
+constexpr int kDeferExtent = 512 * 256; // bigger than this: the deferred (tile) path
+
+// ------------------------------------------------------------------------------
+// Draw cull
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_draw_cull(SceneView sv, FrameView fv) {
+    const uint32_t di = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = lane_id();
+    const rdr_ubo& u = fv.ubo;
+
+    uint32_t ncmd = 0, k_lo = 0, k_hi = 0, lod_meshlet_offset = 0, vis_off = 0;
+    float max_scale = 0.0f;
+    bool emitted = false;
+    if (di < sv.draw_count) {
+        const rdr_mesh_draw d = sv.draws[di];
+        const rdr_mesh* mesh = &sv.meshes[d.mesh_index];
+        float model[16];
+        load_m4(sv.transforms + (size_t)d.model_index * 16, model);
+        const vec4 cw = mul_m4(model, mk4(mesh->center[0], mesh->center[1], mesh->center[2], 1.0f));
+        const vec4 cv = mul_m4(u.view, cw);
+        const vec3 c = mk3(cv.x, cv.y, cv.z);
+        max_scale = model_max_scale(model);
+        const float radius = max_scale * mesh->radius;
+
+        bool visible = true;
+        visible = visible && (c.z * -u.frustum[1] + fabsf(c.x) * u.frustum[0] < radius);
+        visible = visible && (c.z * -u.frustum[3] + fabsf(c.y) * u.frustum[2] < radius);
+        visible = visible && (c.z + radius > -u.near_plane) && (c.z + radius < u.far_plane);
+
+        uint32_t lod = 0xFFu;
+        if (visible || d.alpha_mode == 1u) {
+            uint32_t lod_index = 0;
+            const float threshold = fmaxf(len3(c) - radius, 0.0f) * u.lod_target / max_scale;
+            const uint32_t lod_count = mesh->lod_count;
+            for (uint32_t i = 1; i < lod_count; ++i)
+                if (mesh->lods[i].error < threshold) lod_index = i;
+            lod = u.lod_enabled == 1u ? lod_index : 0u;
+            const rdr_mesh_lod L = mesh->lods[lod];
+            lod_meshlet_offset = L.meshlet_offset;
+            vis_off = d.meshlet_visibility_offset;
+            // this renderer's sort-last share, in meshlet-instance ids
+            const uint32_t lo = max(vis_off, fv.part_lo), hi = min(vis_off + L.meshlet_count, fv.part_hi);
+            if (hi > lo) {
+                k_lo = lo - vis_off;
+                k_hi = hi - vis_off;
+                ncmd = (k_hi - k_lo + 63u) / 64u;
+            }
+            emitted = true;
+        }
+        sv.draw_lod[di] = (uint8_t)lod;
+    }
+
+    // wave-level compaction: one atomic per wave reserves the commands of 64 draws
+    const uint32_t incl = wave_scan_inclusive(ncmd, lane);
+    const uint32_t total = __shfl(incl, 63, 64);
+    uint32_t base = 0;
+    if (lane == 0 && total) base = atomicAdd(&fv.counters->cmd_count, total);
+    base = __shfl(base, 0, 64);
+    uint32_t slot = base + incl - ncmd;
+    for (uint32_t i = 0; i < ncmd; ++i, ++slot) {
+        if (slot >= fv.command_capacity) break;
+        CullCommand cmd;
+        cmd.draw_id = di;
+        cmd.meshlet_first = lod_meshlet_offset + k_lo + i * 64u;
+        cmd.count = min(64u, k_hi - k_lo - i * 64u);
+        cmd.instance_first = vis_off + k_lo + i * 64u;
+        cmd.max_scale = max_scale;
+        cmd._pad[0] = cmd._pad[1] = cmd._pad[2] = 0;
+        fv.commands[slot] = cmd;
+    }
+    if (fv.collect_stats) {
+        const uint32_t n = wave_sum(emitted ? 1u : 0u);
+        if (lane == 0 && n) atomicAdd(&fv.counters->draws_visible, (unsigned long long)n);
+    }
+}
+
+// ------------------------------------------------------------------------------
+// Meshlet cull: one wave per command, one lane per meshlet.
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_meshlet_cull(SceneView sv, FrameView fv) {
+    const uint32_t lane = lane_id();
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const rdr_ubo& u = fv.ubo;
+    const uint32_t cmd_count = min(fv.counters->cmd_count, fv.command_capacity);
+
+    unsigned long long st_tested = 0, st_visible = 0, st_tris = 0;
+    for (uint32_t ci = wave; ci < cmd_count; ci += n_waves) {
+        const CullCommand* cp = &fv.commands[__builtin_amdgcn_readfirstlane(ci)];
+        const uint32_t draw_id = cp->draw_id, first = cp->meshlet_first, count = cp->count;
+        const uint32_t instance_first = cp->instance_first;
+        const float max_scale = cp->max_scale;
+        const uint32_t model_index = sv.draws[draw_id].model_index;
+        float model[16];
+        load_m4(sv.transforms + (size_t)model_index * 16, model);
+
+        bool accept = lane < count;
+        uint32_t tri_count = 0;
+        if (accept) {
+            const rdr_meshlet m = sv.meshlets[first + lane];
+            tri_count = m.triangle_count;
+            const vec4 cw = mul_m4(model, mk4(m.center[0], m.center[1], m.center[2], 1.0f));
+            const vec4 cv = mul_m4(u.view, cw);
+            const vec3 cc = mk3(cv.x, cv.y, cv.z);
+            const vec4 aw = mul_m4(model, mk4((float)m.cone_axis[0] / 127.0f, (float)m.cone_axis[1] / 127.0f,
+                                              (float)m.cone_axis[2] / 127.0f, 0.0f));
+            const vec4 av = mul_m4(u.view, aw);
+            const vec3 axis = normalize3(mk3(av.x, av.y, av.z));
+            const float radius = max_scale * m.radius;
+            const float cutoff = (float)m.cone_cutoff / 127.0f;
+            accept = accept && !(dot3(cc, axis) >= cutoff * len3(cc) + radius);
+            accept = accept && (cc.z * -u.frustum[1] + cc.x * u.frustum[0] < radius);
+            accept = accept && (cc.z * -u.frustum[3] + cc.y * u.frustum[2] < radius);
+            accept = accept && (cc.z + radius > -u.near_plane) && (cc.z + radius < u.far_plane);
+        }
+        const unsigned long long mask = __ballot(accept);
+        const uint32_t n_acc = (uint32_t)__popcll(mask);
+        uint32_t base = 0;
+        if (lane == 0 && n_acc) base = atomicAdd(&fv.counters->vis_count, n_acc);
+        base = __shfl(base, 0, 64);
+        if (accept) {
+            const uint32_t slot = base + ballot_rank(mask);
+            if (slot < fv.visible_capacity) {
+                VisibleMeshlet v;
+                v.draw_id = draw_id;
+                v.meshlet_index = first + lane;
+                v.instance = instance_first + lane;
+                v._pad = 0;
+                fv.visible[slot] = v;
+            }
+        }
+        st_tested += count;
+        st_visible += n_acc;
+        st_tris += tri_count;
+    }
+    if (fv.collect_stats) {
+        const unsigned long long t = wave_sum64(st_tris);
+        if (lane == 0) {
+            if (st_tested) atomicAdd(&fv.counters->meshlets_tested, st_tested);
+            if (st_visible) atomicAdd(&fv.counters->meshlets_visible, st_visible);
+            if (t) atomicAdd(&fv.counters->triangles_submitted, t);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------
+// Rasteriser
+// ------------------------------------------------------------------------------
+
+struct AlphaTest {
+    bool enabled, has_tex;
+    uint32_t image, uv_set;
+    float sx, sy, ox, oy, factor_a, cutoff;
+};
+
+RDR_DEV AlphaTest make_alpha_test(const SceneView& sv, const rdr_mesh_draw& d) {
+    AlphaTest at;
+    at.enabled = d.alpha_mode == 1u;
+    at.has_tex = false;
+    at.image = 0; at.uv_set = 0;
+    at.sx = at.sy = at.ox = at.oy = 0.0f;
+    at.factor_a = 0.0f; at.cutoff = 0.0f; // material_index past the end reads zeros
+    if (at.enabled && d.material_index < sv.material_count) {
+        const rdr_material* mat = &sv.materials[d.material_index];
+        at.factor_a = mat->base_color_factor[3];
+        at.cutoff = mat->emissive_factor_alpha_cutoff[3];
+        const uint32_t tex = mat->albedo_texture;
+        if (tex != RDR_NO_TEXTURE && tex < sv.image_count) {
+            at.has_tex = true;
+            at.image = tex;
+            at.uv_set = mat->albedo_texture_uv == 0u ? 0u : 1u;
+            at.sx = mat->albedo_texture_transform[0]; at.sy = mat->albedo_texture_transform[1];
+            at.ox = mat->albedo_texture_transform[2]; at.oy = mat->albedo_texture_transform[3];
+        }
+    }
+    return at;
+}
+
+struct SnapVert {
+    int32_t X, Y; // 24.8 framebuffer position, y down
+    float z;      // z/w
+    float inv_w;
+    float u0, v0, u1, v1;
+};
+
+RDR_DEV void project_xy(float cx, float cy, float cw, float half_w, float half_h, int32_t& X, int32_t& Y) {
+    const float ndcx = cx / cw, ndcy = cy / cw;
+    const float xf = half_w * ndcx + half_w;
+    const float yf = -half_h * ndcy + half_h; // viewport {y = H, height = -H}
+    X = (int32_t)rintf(xf * 256.0f);
+    Y = (int32_t)rintf(yf * 256.0f);
+}
+
+RDR_DEV bool vert_needs_clip(float x, float y, float z, float w) {
+    const float g = kGuardBand * w;
+    return !(w >= z) || !(fabsf(x) <= g) || !(fabsf(y) <= g);
+}
+
+RDR_DEV void emit_fragment(const FrameView& fv, int px, int py, float z, uint32_t id) {
+    z = clampf(z, 0.0f, 1.0f);
+    const unsigned long long key =
+        ((unsigned long long)(0x7FFFFFFFu - __float_as_uint(z)) << 32) | (unsigned long long)id;
+    unsigned long long* p = &fv.vis[(size_t)py * fv.width + px];
+    // cheap pre-test: most fragments of an already covered pixel lose
+    if (key < __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        __hip_atomic_fetch_min(p, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Perspective-correct uv at the sample with edge values (e0, e1, e2).
+template <typename I>
+RDR_DEV void persp_uv(const SnapVert& a, const SnapVert& b, const SnapVert& c, I e0, I e1, I e2, uint32_t set,
+                      float& u, float& v) {
+    const float b0 = (float)e0 * a.inv_w, b1 = (float)e1 * b.inv_w, b2 = (float)e2 * c.inv_w;
+    const float sum = (b0 + b1) + b2;
+    if (set == 0u) {
+        u = ((b0 * a.u0 + b1 * b.u0) + b2 * c.u0) / sum;
+        v = ((b0 * a.v0 + b1 * b.v0) + b2 * c.v0) / sum;
+    } else {
+        u = ((b0 * a.u1 + b1 * b.u1) + b2 * c.u1) / sum;
+        v = ((b0 * a.v1 + b1 * b.v1) + b2 * c.v1) / sum;
+    }
+}
+
+// Triangle set up for scanning: oriented so that the interior has positive edge
+// values, with the top-left rule folded into a bias.
+template <typename I>
+struct TriSetup {
+    SnapVert v0, v1, v2;
+    I dx01, dy01, dx12, dy12, dx20, dy20;
+    int32_t bias01, bias12, bias20; // 0 for top-left edges, -1 otherwise
+    float inv_area, dz1, dz2;
+    int px0, py0, px1, py1;
+    bool valid;
+};
+
+template <typename I>
+RDR_DEV TriSetup<I> setup_triangle(const FrameView& fv, SnapVert v0, SnapVert v1, SnapVert v2, bool cull_front) {
+    TriSetup<I> t;
+    t.valid = false;
+    long long A = (long long)(v1.X - v0.X) * (v2.Y - v0.Y) - (long long)(v1.Y - v0.Y) * (v2.X - v0.X);
+    if (A == 0) return t;
+    if (A > 0) {
+        // clockwise on the y-down screen: front-facing under frontFace = CLOCKWISE
+        if (cull_front) return t;
+    } else {
+        const SnapVert tmp = v1; v1 = v2; v2 = tmp;
+        A = -A;
+    }
+    const int32_t minX = min(v0.X, min(v1.X, v2.X)), maxX = max(v0.X, max(v1.X, v2.X));
+    const int32_t minY = min(v0.Y, min(v1.Y, v2.Y)), maxY = max(v0.Y, max(v1.Y, v2.Y));
+    t.px0 = max((minX - 128 + 255) >> 8, 0);
+    t.px1 = min((maxX - 128) >> 8, (int)fv.width - 1);
+    t.py0 = max((minY - 128 + 255) >> 8, 0);
+    t.py1 = min((maxY - 128) >> 8, (int)fv.height - 1);
+    if (t.px0 > t.px1 || t.py0 > t.py1) return t;
+    t.v0 = v0; t.v1 = v1; t.v2 = v2;
+    t.dx01 = (I)(v1.X - v0.X); t.dy01 = (I)(v1.Y - v0.Y);
+    t.dx12 = (I)(v2.X - v1.X); t.dy12 = (I)(v2.Y - v1.Y);
+    t.dx20 = (I)(v0.X - v2.X); t.dy20 = (I)(v0.Y - v2.Y);
+    t.bias01 = (t.dy01 < 0 || (t.dy01 == 0 && t.dx01 > 0)) ? 0 : -1;
+    t.bias12 = (t.dy12 < 0 || (t.dy12 == 0 && t.dx12 > 0)) ? 0 : -1;
+    t.bias20 = (t.dy20 < 0 || (t.dy20 == 0 && t.dx20 > 0)) ? 0 : -1;
+    t.inv_area = 1.0f / (float)A;
+    t.dz1 = v1.z - v0.z;
+    t.dz2 = v2.z - v0.z;
+    t.valid = true;
+    return t;
+}
+
+// Edge values at the centre of pixel (px, py).
+template <typename I>
+RDR_DEV void edges_at(const TriSetup<I>& t, int px, int py, I& e01, I& e12, I& e20) {
+    const I Px = (I)px * 256 + 128, Py = (I)py * 256 + 128;
+    e01 = t.dx01 * (Py - (I)t.v0.Y) - t.dy01 * (Px - (I)t.v0.X);
+    e12 = t.dx12 * (Py - (I)t.v1.Y) - t.dy12 * (Px - (I)t.v1.X);
+    e20 = t.dx20 * (Py - (I)t.v2.Y) - t.dy20 * (Px - (I)t.v2.X);
+}
+
+// Coverage + alpha + depth + atomic for one sample. Returns 1 when a fragment was produced.
+template <typename I>
+RDR_DEV uint32_t shade_sample(const SceneView& sv, const FrameView& fv, const TriSetup<I>& t, const AlphaTest& at,
+                              int px, int py, I e01, I e12, I e20, uint32_t id) {
+    if (((e01 + (I)t.bias01) | (e12 + (I)t.bias12) | (e20 + (I)t.bias20)) < 0) return 0;
+    if (at.enabled) {
+        float alpha = 1.0f;
+        if (at.has_tex) {
+            float u, v, ux, vx, uy, vy;
+            persp_uv<I>(t.v0, t.v1, t.v2, e12, e20, e01, at.uv_set, u, v);
+            persp_uv<I>(t.v0, t.v1, t.v2, e12 - t.dy12 * 256, e20 - t.dy20 * 256, e01 - t.dy01 * 256, at.uv_set, ux, vx);
+            persp_uv<I>(t.v0, t.v1, t.v2, e12 + t.dx12 * 256, e20 + t.dx20 * 256, e01 + t.dx01 * 256, at.uv_set, uy, vy);
+            u = u * at.sx + at.ox; v = v * at.sy + at.oy;
+            ux = ux * at.sx + at.ox; vx = vx * at.sy + at.oy;
+            uy = uy * at.sx + at.ox; vy = vy * at.sy + at.oy;
+            alpha = image_sample_grad(sv.images[at.image], sv.texels, sv.srgb_lut, u, v, ux - u, vx - v, uy - u, vy - v).w;
+        }
+        alpha = alpha * at.factor_a;
+        if (alpha < at.cutoff) return 0;
+    }
+    const float l1 = (float)e20 * t.inv_area, l2 = (float)e01 * t.inv_area;
+    const float z = fmaf(l2, t.dz2, fmaf(l1, t.dz1, t.v0.z));
+    emit_fragment(fv, px, py, z, id);
+    return 1;
+}
+
+// One lane scans the whole bounding box.
+template <typename I>
+RDR_DEV uint32_t scan_lane(const SceneView& sv, const FrameView& fv, const TriSetup<I>& t, const AlphaTest& at, uint32_t id) {
+    uint32_t frags = 0;
+    I r01, r12, r20;
+    edges_at<I>(t, t.px0, t.py0, r01, r12, r20);
+    for (int py = t.py0; py <= t.py1; ++py) {
+        I e01 = r01, e12 = r12, e20 = r20;
+        for (int px = t.px0; px <= t.px1; ++px) {
+            frags += shade_sample<I>(sv, fv, t, at, px, py, e01, e12, e20, id);
+            e01 -= t.dy01 * 256; e12 -= t.dy12 * 256; e20 -= t.dy20 * 256;
+        }
+        r01 += t.dx01 * 256; r12 += t.dx12 * 256; r20 += t.dx20 * 256;
+    }
+    return frags;
+}
+
+// All 64 lanes scan one triangle: 8x8 pixel blocks swept over the bounding box.
+// `t` and `id` must be wave-uniform.
+template <typename I>
+RDR_DEV uint32_t scan_wave(const SceneView& sv, const FrameView& fv, const TriSetup<I>& t, const AlphaTest& at,
+                           uint32_t id, uint32_t lane) {
+    uint32_t frags = 0;
+    const int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
+    for (int by = t.py0 & ~7; by <= t.py1; by += 8) {
+        const int py = by + ly;
+        for (int bx = t.px0 & ~7; bx <= t.px1; bx += 8) {
+            const int px = bx + lx;
+            if (px < t.px0 || px > t.px1 || py < t.py0 || py > t.py1) continue;
+            I e01, e12, e20;
+            edges_at<I>(t, px, py, e01, e12, e20);
+            frags += shade_sample<I>(sv, fv, t, at, px, py, e01, e12, e20, id);
+        }
+    }
+    return frags;
+}
+
+// Per-wave LDS: the transformed vertices of one meshlet.
+struct MeshletLds {
+    float cx[64], cy[64], cz[64], cw[64]; // clip space
+    float sx[64], sy[64];                 // the mesh shader's y-up screen position
+    int32_t X[64], Y[64];                 // snapped framebuffer position
+    uint32_t clip[64];                    // vertex is outside the near plane / guard band
+};
+
+__global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
+    __shared__ MeshletLds lds;
+    const uint32_t lane = threadIdx.x;
+    const rdr_ubo& u = fv.ubo;
+    const uint32_t vis_count = min(fv.counters->vis_count, fv.visible_capacity);
+    const float half_w = (float)fv.width * 0.5f, half_h = (float)fv.height * 0.5f;
+
+    uint32_t st_tested = 0, st_raster = 0, st_big = 0, st_frags = 0;
+    for (uint32_t mi = blockIdx.x; mi < vis_count; mi += gridDim.x) {
+        const VisibleMeshlet vm = fv.visible[mi];
+        const rdr_mesh_draw d = sv.draws[vm.draw_id];
+        const rdr_meshlet m = sv.meshlets[vm.meshlet_index];
+        const uint32_t mesh_vertex_offset = sv.meshes[d.mesh_index].vertex_offset;
+        float model[16];
+        load_m4(sv.transforms + (size_t)d.model_index * 16, model);
+        const AlphaTest at = make_alpha_test(sv, d);
+        const bool cull_front = d.alpha_mode == 0u;
+
+        __syncthreads(); // previous meshlet's readers are done
+        if (lane < m.vertex_count) {
+            const uint32_t vi = sv.meshlet_vertices[m.vertex_offset + lane] + mesh_vertex_offset;
+            const vec4 world = mul_m4(model, mk4(sv.pos_x[vi], sv.pos_y[vi], sv.pos_z[vi], 1.0f));
+            const vec4 clip = mul_m4(u.view_proj, world);
+            lds.cx[lane] = clip.x; lds.cy[lane] = clip.y; lds.cz[lane] = clip.z; lds.cw[lane] = clip.w;
+            lds.sx[lane] = (clip.x / clip.w * 0.5f + 0.5f) * u.screen_width;
+            lds.sy[lane] = (clip.y / clip.w * 0.5f + 0.5f) * u.screen_height;
+            const bool nc = vert_needs_clip(clip.x, clip.y, clip.z, clip.w);
+            int32_t X = 0, Y = 0;
+            if (!nc) project_xy(clip.x, clip.y, clip.w, half_w, half_h, X, Y);
+            lds.X[lane] = X; lds.Y[lane] = Y;
+            lds.clip[lane] = nc ? 1u : 0u;
+        }
+        __syncthreads();
+
+        for (uint32_t t0 = 0; t0 < m.triangle_count; t0 += 64) {
+            const uint32_t ti = t0 + lane;
+            // 0 = nothing, 1 = wave-cooperative, 2 = deferred
+            uint32_t route = 0;
+            TriSetup<int32_t> ts;
+            ts.valid = false;
+            uint32_t ia = 0, ib = 0, ic = 0;
+            if (ti < m.triangle_count) {
+                const uint8_t* tp = sv.meshlet_triangles + m.triangle_offset + ti * 3;
+                ia = tp[0]; ib = tp[1]; ic = tp[2];
+                st_tested++;
+                const float ax = lds.sx[ia], ay = lds.sy[ia], bx = lds.sx[ib], by = lds.sy[ib];
+                const float cx = lds.sx[ic], cy = lds.sy[ic];
+                const float ebax = bx - ax, ebay = by - ay, ecax = cx - ax, ecay = cy - ay;
+                bool culled = ebax * ecay <= ebay * ecax;
+                const float bminx = fminf(ax, fminf(bx, cx)), bminy = fminf(ay, fminf(by, cy));
+                const float bmaxx = fmaxf(ax, fmaxf(bx, cx)), bmaxy = fmaxf(ay, fmaxf(by, cy));
+                const float sbprec = 1.0f / 256.0f;
+                culled = culled || (rintf(bminx - sbprec) == rintf(bmaxx) || rintf(bminy) == rintf(bmaxy + sbprec));
+                culled = culled && (lds.cw[ia] > 0.0f && lds.cw[ib] > 0.0f && lds.cw[ic] > 0.0f);
+                if (!culled) {
+                    st_raster++;
+                    if (lds.clip[ia] | lds.clip[ib] | lds.clip[ic]) {
+                        route = 2;
+                    } else {
+                        const int32_t X0 = lds.X[ia], X1 = lds.X[ib], X2 = lds.X[ic];
+                        const int32_t Y0 = lds.Y[ia], Y1 = lds.Y[ib], Y2 = lds.Y[ic];
+                        const int32_t ex = max(X0, max(X1, X2)) - min(X0, min(X1, X2));
+                        const int32_t ey = max(Y0, max(Y1, Y2)) - min(Y0, min(Y1, Y2));
+                        if (ex > kDeferExtent || ey > kDeferExtent) {
+                            route = 2;
+                        } else {
+                            SnapVert s0, s1, s2;
+                            s0.X = X0; s0.Y = Y0; s0.z = lds.cz[ia] / lds.cw[ia];
+                            s1.X = X1; s1.Y = Y1; s1.z = lds.cz[ib] / lds.cw[ib];
+                            s2.X = X2; s2.Y = Y2; s2.z = lds.cz[ic] / lds.cw[ic];
+                            s0.inv_w = s1.inv_w = s2.inv_w = 0.0f;
+                            s0.u0 = s0.v0 = s0.u1 = s0.v1 = 0.0f;
+                            s1.u0 = s1.v0 = s1.u1 = s1.v1 = 0.0f;
+                            s2.u0 = s2.v0 = s2.u1 = s2.v1 = 0.0f;
+                            if (at.enabled && at.has_tex) {
+                                const uint32_t* mv = sv.meshlet_vertices + m.vertex_offset;
+                                const rdr_vertex* va = &sv.vertices[mv[ia] + mesh_vertex_offset];
+                                const rdr_vertex* vb = &sv.vertices[mv[ib] + mesh_vertex_offset];
+                                const rdr_vertex* vc = &sv.vertices[mv[ic] + mesh_vertex_offset];
+                                s0.inv_w = 1.0f / lds.cw[ia]; s1.inv_w = 1.0f / lds.cw[ib]; s2.inv_w = 1.0f / lds.cw[ic];
+                                s0.u0 = va->uv[0]; s0.v0 = va->uv[1]; s0.u1 = va->uv[2]; s0.v1 = va->uv[3];
+                                s1.u0 = vb->uv[0]; s1.v0 = vb->uv[1]; s1.u1 = vb->uv[2]; s1.v1 = vb->uv[3];
+                                s2.u0 = vc->uv[0]; s2.v0 = vc->uv[1]; s2.u1 = vc->uv[2]; s2.v1 = vc->uv[3];
+                            }
+                            if (ex <= kSmallExtent && ey <= kSmallExtent) {
+                                ts = setup_triangle<int32_t>(fv, s0, s1, s2, cull_front);
+                                if (ts.valid) {
+                                    const int npx = (ts.px1 - ts.px0 + 1) * (ts.py1 - ts.py0 + 1);
+                                    if (npx > kLaneMaxPixels) route = 1;
+                                    else st_frags += scan_lane<int32_t>(sv, fv, ts, at, (vm.instance << 7) | ti);
+                                }
+                            } else {
+                                route = 3; // medium: wave-cooperative in 64-bit
+                            }
+                        }
+                    }
+                }
+            }
+            // deferred triangles: reserve slots with one atomic per wave
+            {
+                const unsigned long long dm = __ballot(route == 2);
+                if (dm) {
+                    const uint32_t n = (uint32_t)__popcll(dm);
+                    uint32_t base = 0;
+                    if (lane == (uint32_t)__ffsll((long long)dm) - 1u) base = atomicAdd(&fv.counters->deferred_count, n);
+                    base = __shfl(base, __ffsll((long long)dm) - 1, 64);
+                    if (route == 2) {
+                        const uint32_t slot = base + ballot_rank(dm);
+                        if (slot < fv.deferred_capacity) {
+                            DeferredTriangle* dt = &fv.deferred[slot];
+                            const uint32_t idx[3] = {ia, ib, ic};
+                            const uint32_t* mv = sv.meshlet_vertices + m.vertex_offset;
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) {
+                                dt->pos[k][0] = lds.cx[idx[k]]; dt->pos[k][1] = lds.cy[idx[k]];
+                                dt->pos[k][2] = lds.cz[idx[k]]; dt->pos[k][3] = lds.cw[idx[k]];
+                                const rdr_vertex* vv = &sv.vertices[mv[idx[k]] + mesh_vertex_offset];
+                                dt->uv[k][0] = vv->uv[0]; dt->uv[k][1] = vv->uv[1];
+                                dt->uv[k][2] = vv->uv[2]; dt->uv[k][3] = vv->uv[3];
+                            }
+                            dt->id = (vm.instance << 7) | ti;
+                            dt->draw_id = vm.draw_id;
+                            dt->_pad[0] = dt->_pad[1] = 0;
+                        } else {
+                            atomicAdd(&fv.counters->deferred_overflow, 1u);
+                        }
+                        st_big++;
+                    }
+                }
+            }
+            // wave-cooperative triangles, one at a time, parameters broadcast from the owner lane
+            unsigned long long wm = __ballot(route == 1 || route == 3);
+            while (wm) {
+                const int src = __ffsll((long long)wm) - 1;
+                wm &= wm - 1;
+                const uint32_t sti = t0 + (uint32_t)src;
+                const uint8_t* tp = sv.meshlet_triangles + m.triangle_offset + sti * 3;
+                const uint32_t ja = tp[0], jb = tp[1], jc = tp[2];
+                SnapVert s0, s1, s2;
+                s0.X = lds.X[ja]; s0.Y = lds.Y[ja]; s0.z = lds.cz[ja] / lds.cw[ja];
+                s1.X = lds.X[jb]; s1.Y = lds.Y[jb]; s1.z = lds.cz[jb] / lds.cw[jb];
+                s2.X = lds.X[jc]; s2.Y = lds.Y[jc]; s2.z = lds.cz[jc] / lds.cw[jc];
+                s0.inv_w = s1.inv_w = s2.inv_w = 0.0f;
+                s0.u0 = s0.v0 = s0.u1 = s0.v1 = 0.0f;
+                s1.u0 = s1.v0 = s1.u1 = s1.v1 = 0.0f;
+                s2.u0 = s2.v0 = s2.u1 = s2.v1 = 0.0f;
+                if (at.enabled && at.has_tex) {
+                    const uint32_t* mv = sv.meshlet_vertices + m.vertex_offset;
+                    const rdr_vertex* va = &sv.vertices[mv[ja] + mesh_vertex_offset];
+                    const rdr_vertex* vb = &sv.vertices[mv[jb] + mesh_vertex_offset];
+                    const rdr_vertex* vc = &sv.vertices[mv[jc] + mesh_vertex_offset];
+                    s0.inv_w = 1.0f / lds.cw[ja]; s1.inv_w = 1.0f / lds.cw[jb]; s2.inv_w = 1.0f / lds.cw[jc];
+                    s0.u0 = va->uv[0]; s0.v0 = va->uv[1]; s0.u1 = va->uv[2]; s0.v1 = va->uv[3];
+                    s1.u0 = vb->uv[0]; s1.v0 = vb->uv[1]; s1.u1 = vb->uv[2]; s1.v1 = vb->uv[3];
+                    s2.u0 = vc->uv[0]; s2.v0 = vc->uv[1]; s2.u1 = vc->uv[2]; s2.v1 = vc->uv[3];
+                }
+                const TriSetup<long long> tw = setup_triangle<long long>(fv, s0, s1, s2, cull_front);
+                if (tw.valid) st_frags += scan_wave<long long>(sv, fv, tw, at, (vm.instance << 7) | sti, lane);
+            }
+        }
+    }
+    if (fv.collect_stats) {
+        const uint32_t a = wave_sum(st_tested), b = wave_sum(st_raster), c = wave_sum(st_big), f = wave_sum(st_frags);
+        if (lane == 0) {
+            if (a) atomicAdd(&fv.counters->triangles_tested, (unsigned long long)a);
+            if (b) atomicAdd(&fv.counters->triangles_rasterised, (unsigned long long)b);
+            if (c) atomicAdd(&fv.counters->triangles_big, (unsigned long long)c);
+            if (f) atomicAdd(&fv.counters->fragments, (unsigned long long)f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------
+// Deferred triangles: clip in clip space, then scan with the whole wave.
+// ------------------------------------------------------------------------------
+struct ClipVert {
+    float x, y, z, w, uv[4];
+};
+
+RDR_DEV float plane_dist(const ClipVert& v, int plane) {
+    switch (plane) {
+    case 0: return v.w - v.z;
+    case 1: return kGuardBand * v.w - v.x;
+    case 2: return kGuardBand * v.w + v.x;
+    case 3: return kGuardBand * v.w - v.y;
+    default: return kGuardBand * v.w + v.y;
+    }
+}
+
+// New vertex on the plane, always interpolated from the inside vertex.
+RDR_DEV ClipVert clip_lerp(const ClipVert& in, const ClipVert& out, float din, float dout) {
+    const float t = din / (din - dout);
+    ClipVert r;
+    r.x = in.x + t * (out.x - in.x);
+    r.y = in.y + t * (out.y - in.y);
+    r.z = in.z + t * (out.z - in.z);
+    r.w = in.w + t * (out.w - in.w);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.uv[k] = in.uv[k] + t * (out.uv[k] - in.uv[k]);
+    return r;
+}
+
+RDR_DEV SnapVert snap_clip_vert(const ClipVert& v, float half_w, float half_h) {
+    SnapVert s;
+    project_xy(v.x, v.y, v.w, half_w, half_h, s.X, s.Y);
+    s.z = v.z / v.w;
+    s.inv_w = 1.0f / v.w;
+    s.u0 = v.uv[0]; s.v0 = v.uv[1]; s.u1 = v.uv[2]; s.v1 = v.uv[3];
+    return s;
+}
+
+__global__ __launch_bounds__(64) void k_deferred(SceneView sv, FrameView fv) {
+    __shared__ ClipVert poly[12];
+    __shared__ ClipVert tmp[12];
+    __shared__ int n_shared;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t count = min(fv.counters->deferred_count, fv.deferred_capacity);
+    const float half_w = (float)fv.width * 0.5f, half_h = (float)fv.height * 0.5f;
+    uint32_t st_frags = 0;
+    for (uint32_t di = blockIdx.x; di < count; di += gridDim.x) {
+        const DeferredTriangle* dt = &fv.deferred[di];
+        const rdr_mesh_draw d = sv.draws[dt->draw_id];
+        const AlphaTest at = make_alpha_test(sv, d);
+        const bool cull_front = d.alpha_mode == 0u;
+        const uint32_t id = dt->id;
+        __syncthreads();
+        if (lane == 0) {
+            // Sutherland-Hodgman against near + the four guard-band planes (serial, tiny)
+            int n = 3;
+            for (int k = 0; k < 3; ++k) {
+                poly[k].x = dt->pos[k][0]; poly[k].y = dt->pos[k][1]; poly[k].z = dt->pos[k][2]; poly[k].w = dt->pos[k][3];
+                for (int j = 0; j < 4; ++j) poly[k].uv[j] = dt->uv[k][j];
+            }
+            const bool needs = vert_needs_clip(poly[0].x, poly[0].y, poly[0].z, poly[0].w) ||
+                               vert_needs_clip(poly[1].x, poly[1].y, poly[1].z, poly[1].w) ||
+                               vert_needs_clip(poly[2].x, poly[2].y, poly[2].z, poly[2].w);
+            if (needs) {
+                for (int plane = 0; plane < 5 && n > 0; ++plane) {
+                    int mcount = 0;
+                    for (int i = 0; i < n; ++i) {
+                        const ClipVert& p = poly[i];
+                        const ClipVert& q = poly[(i + 1) % n];
+                        const float dp = plane_dist(p, plane), dq = plane_dist(q, plane);
+                        const bool pin = dp >= 0.0f, qin = dq >= 0.0f;
+                        if (pin) tmp[mcount++] = p;
+                        if (pin && !qin) tmp[mcount++] = clip_lerp(p, q, dp, dq);
+                        else if (!pin && qin) tmp[mcount++] = clip_lerp(q, p, dq, dp);
+                    }
+                    for (int i = 0; i < mcount; ++i) poly[i] = tmp[i];
+                    n = mcount;
+                }
+            }
+            n_shared = n;
+        }
+        __syncthreads();
+        const int n = n_shared;
+        if (n < 3) continue;
+        const SnapVert s0 = snap_clip_vert(poly[0], half_w, half_h);
+        SnapVert sp = snap_clip_vert(poly[1], half_w, half_h);
+        for (int i = 2; i < n; ++i) {
+            const SnapVert sn = snap_clip_vert(poly[i], half_w, half_h);
+            const TriSetup<long long> tw = setup_triangle<long long>(fv, s0, sp, sn, cull_front);
+            if (tw.valid) st_frags += scan_wave<long long>(sv, fv, tw, at, id, lane);
+            sp = sn;
+        }
+    }
+    if (fv.collect_stats) {
+        const uint32_t f = wave_sum(st_frags);
+        if (lane == 0 && f) atomicAdd(&fv.counters->fragments, (unsigned long long)f);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_clear(unsigned long long* vis, size_t n, FrameCounters* counters) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i + 1 < n) {
+        *reinterpret_cast<ulonglong2*>(vis + i) = make_ulonglong2(RDR_VIS_CLEAR, RDR_VIS_CLEAR);
+    } else if (i < n) {
+        vis[i] = RDR_VIS_CLEAR;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(FrameCounters) / 4) reinterpret_cast<uint32_t*>(counters)[threadIdx.x] = 0u;
+}
+
+// Packed key -> the reference's visibility-buffer texel
+// (assets/shaders/shader.frag.glsl:71-74; clear value renderer/src/renderer/pass.rs:250).
+__global__ __launch_bounds__(256) void k_resolve(SceneView sv, FrameView fv, uint32_t* out_xy) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)fv.width * fv.height) return;
+    const unsigned long long key = fv.vis[i];
+    uint32_t x = 0xFFFFFFFFu, y = 0xFFFFFFFFu;
+    if (key != RDR_VIS_CLEAR) {
+        const uint32_t id = (uint32_t)key, instance = id >> 7, tri = id & 127u;
+        const uint32_t draw_id = sv.instance_draw[instance];
+        const rdr_mesh_draw d = sv.draws[draw_id];
+        const rdr_mesh_lod L = sv.meshes[d.mesh_index].lods[sv.draw_lod[draw_id]];
+        x = ((L.meshlet_offset + (instance - d.meshlet_visibility_offset)) << 8) | tri;
+        y = draw_id;
+    }
+    reinterpret_cast<uint2*>(out_xy)[i] = make_uint2(x, y);
+}
+
+} // namespace
+
+int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev) {
+    const size_t npx = (size_t)fv.width * fv.height;
+    const uint32_t clear_blocks = (uint32_t)((npx / 2 + 1 + 255) / 256);
+    if (ev) RDR_HIP(hipEventRecord(ev[0], stream));
+    hipLaunchKernelGGL(k_clear, dim3(clear_blocks), dim3(256), 0, stream, fv.vis, npx, fv.counters);
+    if (ev) RDR_HIP(hipEventRecord(ev[1], stream));
+    if (sv.draw_count) {
+        hipLaunchKernelGGL(k_draw_cull, dim3((sv.draw_count + 255) / 256), dim3(256), 0, stream, sv, fv);
+        if (ev) RDR_HIP(hipEventRecord(ev[2], stream));
+        // persistent grids: the work-list lengths live in device memory
+        const uint32_t cull_blocks = max(1u, min((fv.command_capacity + 3) / 4, 2048u));
+        hipLaunchKernelGGL(k_meshlet_cull, dim3(cull_blocks), dim3(256), 0, stream, sv, fv);
+        if (ev) RDR_HIP(hipEventRecord(ev[3], stream));
+        const uint32_t raster_blocks = max(1u, min(fv.visible_capacity, 256u * 32u));
+        hipLaunchKernelGGL(k_raster, dim3(raster_blocks), dim3(64), 0, stream, sv, fv);
+        if (ev) RDR_HIP(hipEventRecord(ev[4], stream));
+        hipLaunchKernelGGL(k_deferred, dim3(2048), dim3(64), 0, stream, sv, fv);
+        if (ev) RDR_HIP(hipEventRecord(ev[5], stream));
+    }
+    RDR_HIP(hipGetLastError());
+    return 0;
+}
+
+int rdr_launch_resolve(const SceneView& sv, const FrameView& fv, uint32_t* out_xy, hipStream_t stream) {
+    const size_t npx = (size_t)fv.width * fv.height;
+    hipLaunchKernelGGL(k_resolve, dim3((uint32_t)((npx + 255) / 256)), dim3(256), 0, stream, sv, fv, out_xy);
+    RDR_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,175 @@
+// rdr_internal.h — shared declarations of librdr_hip.so (host side).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/rdr_abi.h"
+
+// ---- error plumbing ---------------------------------------------------------
+void rdr_set_error(const std::string& msg);
+#define RDR_HIP(call)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            rdr_set_error(std::string(#call) + " failed: " + hipGetErrorString(e_) + " at " + \
+                          __FILE__ + ":" + std::to_string(__LINE__));                        \
+            return 1;                                                                        \
+        }                                                                                    \
+    } while (0)
+#define RDR_CHECK(cond, msg)            \
+    do {                                \
+        if (!(cond)) {                  \
+            rdr_set_error(msg);         \
+            return 1;                   \
+        }                               \
+    } while (0)
+
+// ---- device-side records ----------------------------------------------------
+
+// One unit of per-meshlet culling work: up to 64 consecutive meshlets of one draw.
+struct CullCommand {
+    uint32_t draw_id;
+    uint32_t meshlet_first;  // global meshlet index of lane 0
+    uint32_t count;          // 1..64
+    uint32_t instance_first; // meshlet-instance id of lane 0
+    float max_scale;         // largest column length of the draw's model matrix
+    uint32_t _pad[3];
+};
+static_assert(sizeof(CullCommand) == 32, "CullCommand must be 32 bytes");
+
+// A meshlet that survived culling, input of the rasteriser.
+struct VisibleMeshlet {
+    uint32_t draw_id;
+    uint32_t meshlet_index;
+    uint32_t instance;
+    uint32_t _pad;
+};
+
+// A triangle the per-meshlet rasteriser hands to the clip / tile path: its three
+// clip-space vertices (position + both uv sets) and its identity.
+struct DeferredTriangle {
+    float pos[3][4];
+    float uv[3][4];
+    uint32_t id;      // (instance << 7) | triangle
+    uint32_t draw_id; // for the alpha test
+    uint32_t _pad[2];
+};
+static_assert(sizeof(DeferredTriangle) == 112, "DeferredTriangle layout");
+
+// Frame counters, one cache line apart from the work-list heads.
+struct FrameCounters {
+    uint32_t cmd_count;
+    uint32_t vis_count;
+    uint32_t deferred_count;
+    uint32_t deferred_overflow;
+    uint32_t _pad0[12];
+    unsigned long long draws_visible;
+    unsigned long long meshlets_tested;
+    unsigned long long meshlets_visible;
+    unsigned long long triangles_submitted;
+    unsigned long long triangles_tested;
+    unsigned long long triangles_rasterised;
+    unsigned long long triangles_big;
+    unsigned long long fragments;
+    unsigned long long pixels_covered;
+    unsigned long long _pad1[7];
+};
+static_assert(sizeof(FrameCounters) == 192, "FrameCounters layout");
+
+struct GpuImage {
+    uint32_t width, height, mip_count, format;
+    uint32_t level_offset[17]; // byte offset of each level from `offset`
+    uint32_t _pad[3];
+    uint64_t offset;           // byte offset into the texel blob
+    uint64_t _pad2;
+};
+
+struct GpuCubemap {
+    uint32_t size, mip_count, format, _pad;
+    uint32_t level_offset[17];
+    uint32_t _pad1[3];
+    uint64_t offset;
+    uint64_t _pad2;
+};
+
+struct BvhNode {
+    float lo[3];
+    int32_t left; // inner: index of left child (right = left + 1); leaf: first item
+    float hi[3];
+    int32_t count; // 0 = inner node
+};
+static_assert(sizeof(BvhNode) == 32, "BvhNode layout");
+
+struct GpuInstance {
+    float inv[12];      // rows of the inverse affine model matrix
+    uint32_t blas_root; // node index of the mesh's BLAS root
+    uint32_t tri_base;  // first triangle of the mesh in the BLAS triangle array
+    uint32_t _pad[2];
+};
+
+// Everything the kernels read, passed by value.
+struct SceneView {
+    const rdr_vertex* vertices;
+    const float* pos_x;
+    const float* pos_y;
+    const float* pos_z;
+    const uint32_t* meshlet_vertices;
+    const uint8_t* meshlet_triangles;
+    const rdr_meshlet* meshlets;
+    const rdr_mesh* meshes;
+    const rdr_mesh_draw* draws;
+    const rdr_material* materials;
+    const float* transforms;
+    const uint32_t* instance_draw; // meshlet instance -> draw id
+    uint8_t* draw_lod;             // per frame: LOD each draw selected, 0xFF = not drawn
+    const GpuImage* images;
+    const uint8_t* texels;
+    const float* srgb_lut;
+    uint32_t draw_count, material_count, image_count, meshlet_count;
+    // shadow-ray structure
+    const BvhNode* tlas;
+    const BvhNode* blas;
+    const uint32_t* tlas_items;
+    const float* blas_tris; // 9 floats per triangle, leaf order
+    const GpuInstance* instances;
+    // environment
+    GpuImage brdf_lut;
+    GpuCubemap lambertian, ggx, charlie;
+};
+
+struct FrameView {
+    rdr_ubo ubo;
+    unsigned long long* vis;
+    uint8_t* color;
+    CullCommand* commands;
+    VisibleMeshlet* visible;
+    DeferredTriangle* deferred;
+    FrameCounters* counters;
+    uint32_t width, height;
+    uint32_t part_lo, part_hi;
+    uint32_t row_lo, row_hi;
+    uint32_t command_capacity, visible_capacity, deferred_capacity;
+    uint32_t collect_stats;
+};
+
+// ---- host BVH builder (rdr_bvh.cpp) -----------------------------------------
+struct HostBvh {
+    std::vector<BvhNode> blas_nodes;
+    std::vector<float> blas_tris;
+    std::vector<uint32_t> mesh_root;     // per mesh
+    std::vector<uint32_t> mesh_tri_base; // per mesh
+    std::vector<BvhNode> tlas_nodes;
+    std::vector<uint32_t> tlas_items;
+    std::vector<GpuInstance> instances;
+};
+void rdr_build_blas(const rdr_scene_desc& s, HostBvh& out);
+void rdr_build_tlas(const rdr_scene_desc& s, const float* transforms, HostBvh& io);
+
+// ---- kernel launchers (rdr_geometry.hip / rdr_shade.hip) ---------------------
+struct KernelTimers;
+int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev);
+int rdr_launch_shade(const SceneView& sv, const FrameView& fv, hipStream_t stream);
+int rdr_launch_resolve(const SceneView& sv, const FrameView& fv, uint32_t* out_xy, hipStream_t stream);
