@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Benchmark of the per-frame hot path: cull -> raster to the 64-bit visibility buffer ->
+(sort-last composite) -> deferred PBR shade -> sRGB store.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A step is one frame with the scene already resident in HBM.  The workload is the instanced
+icosphere field at 3840x2160 ("Field-S": 1 250 instances x 20 480 triangles = 25.6 M triangles
+per GPU), the stand-in for the Sponza / Bistro configurations whose assets do not ship with the
+reference.  With N > 1 each rank (one process per GPU, launched by torch.distributed.run) renders
+its share of an N-times larger field (weak scaling), the full-frame visibility buffers are
+composited with a 64-bit MIN all-reduce over RCCL, every rank shades H/N rows and the RGBA8 rows
+are all-gathered.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def algorithmic_bytes(st, width, height, draws):
+    """Bytes each kernel must move per frame, from the frame's own counters: struct sizes are
+    the reference's GPU layouts (16 B draw, 64 B transform, 160 B mesh, 32 B meshlet, 32 B cull
+    command, 16 B visible-meshlet record, 4 B vertex id + 12 B position, 3 B per triangle,
+    8 B per visibility key, 64 B vertex, 4 B RGBA8)."""
+    px = width * height
+    return {
+        "clear": px * 8,
+        "draw_cull": draws * (16 + 64 + 160) + st["commands"] * 32,
+        "meshlet_cull": st["commands"] * 32 + st["meshlets_tested"] * 32 + st["meshlets_visible"] * 16,
+        "raster": st["meshlets_visible"] * (16 + 32) + st["vertices_transformed"] * (4 + 12)
+                  + st["triangles_tested"] * 3 + st["fragments"] * 8,
+        "shade": px * 8 + st["pixels_covered"] * (15 + 3 * 64) + px * 4,
+    }
+
+
+def cpu_baseline(scene, width, height, frames):
+    """The CPU oracle (a restatement of the reference path, not lavapipe) on this host's cores."""
+    from oracle import orc
+    from renderer_amd import RendererConfig
+    o = orc.OracleRenderer(width, height, RendererConfig())
+    o.set_scene(scene)
+    o.render()  # warm-up (page-in, thread pool)
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        o.render()
+    dt = (time.perf_counter() - t0) / frames
+    return dt, orc.num_threads()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--instances", type=int, default=1250, help="instances per GPU")
+    ap.add_argument("--subdivisions", type=int, default=5)
+    ap.add_argument("--cpu-frames", type=int, default=3, help="CPU-baseline frames (0 = skip)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="run the composite / gather collectives even with one rank (rehearsal)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from renderer_amd import Renderer, RendererConfig, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    multi = world > 1 or args.force_collectives
+    if multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    W, H = args.width, args.height
+    scene = synth.make_field(args.instances * world, args.subdivisions, lods=1, with_env=True)
+    tris_per_frame = scene.triangle_count()
+    conf = RendererConfig(lod_enabled=False, cull_enabled=True, collect_stats=True, time_kernels=True)
+    r = Renderer(W, H, conf, device=local_rank)
+    r.set_scene(scene)
+    stream = torch.cuda.current_stream()
+    r.set_stream(stream.cuda_stream)  # kernels run on torch's stream: ordered with the collectives
+
+    n_inst = scene.meshlet_visibility_count
+    rows = [(H * k) // world for k in range(world + 1)]
+    if multi:
+        r.set_partition(n_inst * rank // world, n_inst * (rank + 1) // world)
+        r.set_shade_rows(rows[rank], rows[rank + 1])
+        vis = torch.as_tensor(r.visbuffer_device_array(), device="cuda")  # int64 view, zero copy
+        color = torch.as_tensor(r.color_device_array(), device="cuda")
+        assert vis.data_ptr() == r.visbuffer_device_array().__cuda_array_interface__["data"][0]
+        even = all(rows[k + 1] - rows[k] == rows[1] for k in range(world))
+
+    def step():
+        r.render_visbuffer()
+        if multi:
+            # keys never set bit 63, so MIN over int64 is the unsigned 64-bit min
+            dist.all_reduce(vis, op=dist.ReduceOp.MIN)
+        r.shade()
+        if multi:
+            mine = color[rows[rank]:rows[rank + 1]]
+            if even:
+                # in place: this rank's rows already sit at their offset of the output
+                dist.all_gather_into_tensor(color.view(-1), mine.reshape(-1))
+            else:
+                dist.all_gather([color[rows[k]:rows[k + 1]] for k in range(world)], mine.clone())
+
+    for _ in range(args.warmup):
+        step()
+    r.sync()
+    r.stats()  # drop the warm-up frames from the kernel timers
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if multi:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if multi:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = r.stats()  # counters of the last frame + mean kernel times over the timed frames
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        fps = args.steps / elapsed
+        kms = st["kernel_ms"]
+        ab = algorithmic_bytes(st, W, H, len(scene.mesh_draws))
+        dom = max(("raster", "shade", "meshlet_cull", "clear", "draw_cull"), key=lambda k: kms[k])
+        if dom == "raster":
+            ab_dom, t_dom = ab["raster"], kms["raster"]
+        else:
+            ab_dom, t_dom = ab[dom], kms[dom]
+        achieved = ab_dom / (t_dom * 1e-3) / 1e9 if t_dom > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("workload") == [args.instances, args.subdivisions, W, H] and world == 1:
+                    traffic = rec.get("kernels", {}).get(dom)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mtri/s",
+            "value": tris_per_frame * fps / 1e6,
+            "unit": "Mtri/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms,
+            "frames_per_s": fps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32+u64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"field: {args.instances} instances/GPU x icosphere-{args.subdivisions} "
+                            f"({tris_per_frame / 1e6:.1f} Mtri submitted per frame), {W}x{H}, lod off; "
+                            "stand-in for the Sponza/Bistro 4K configs (assets not shipped)",
+                "instances": args.instances * world, "width": W, "height": H,
+                "parallelism": "single GPU" if world == 1 else f"sort-last x{world}, u64-min all-reduce + row-split shade",
+            },
+            "kernel_ms": {k: round(v, 4) for k, v in kms.items() if v > 0},
+            "frame_counters": {k: st[k] for k in ("draws_visible", "meshlets_tested", "meshlets_visible",
+                                                  "triangles_submitted", "triangles_tested", "triangles_rasterised",
+                                                  "fragments", "pixels_covered", "vertices_transformed")},
+            "roofline": {"kernel": "k_" + dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes": ab_dom, "kernel_ms": t_dom,
+                         "frame_algorithmic_bytes": sum(ab.values()),
+                         "frame_frac": sum(ab.values()) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+        if world == 1 and args.cpu_frames > 0:
+            dt, threads = cpu_baseline(scene, W, H, args.cpu_frames)
+            out["cpu_baseline"] = {"value": tris_per_frame / dt / 1e6, "unit": "Mtri/s", "cores": threads,
+                                   "kind": "port", "frames_per_s": 1.0 / dt,
+                                   "sample": f"{args.cpu_frames} full frames of the same workload "
+                                             "(CPU restatement of the reference path, OpenMP; not lavapipe)"}
+        print(json.dumps(out), flush=True)
+    r.close()
+    if multi:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

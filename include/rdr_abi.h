@@ -237,7 +237,7 @@ enum {
 };
 
 typedef struct rdr_stats {
-    float kernel_ms[RDR_STAT_KERNELS]; /* last frame, valid when time_kernels = 1 */
+    float kernel_ms[RDR_STAT_KERNELS]; /* mean per frame since the previous rdr_get_stats (time_kernels = 1) */
     uint64_t draws_visible;
     uint64_t commands;            /* 64-meshlet cull commands emitted */
     uint64_t meshlets_tested;
@@ -248,6 +248,8 @@ typedef struct rdr_stats {
     uint64_t triangles_big;       /* routed to the clip / tile path */
     uint64_t fragments;           /* 64-bit atomics issued to memory */
     uint64_t pixels_covered;      /* filled by rdr_shade */
+    uint64_t vertices_transformed;/* vertices of visible meshlets */
+    uint64_t frames_timed;        /* frames kernel_ms is averaged over (time_kernels = 1) */
 } rdr_stats;
 
 typedef struct rdr_renderer rdr_renderer;

@@ -126,7 +126,7 @@ typedef struct {
     int W, H;
     uint64_t* vis;
     /* counters (per thread copies are summed by the caller) */
-    uint64_t tris_tested, tris_raster, tris_big, fragments;
+    uint64_t tris_tested, tris_raster, tris_big, fragments, vertices;
 } geo_ctx;
 
 static inline void vis_min(uint64_t* p, uint64_t key) {
@@ -385,6 +385,7 @@ static void draw_meshlet(geo_ctx* c, uint32_t draw_id, uint32_t meshlet_index, u
 
     clip_vert cv[64];
     float scx[64], scy[64];
+    c->vertices += m->vertex_count;
     for (uint32_t i = 0; i < m->vertex_count; ++i) {
         uint32_t vi = s->meshlet_vertices[m->vertex_offset + i] + mesh->vertex_offset;
         const rdr_vertex* vtx = &s->vertices[vi];
@@ -444,10 +445,10 @@ int orc_render_visbuffer(const rdr_scene_desc* s, const rdr_ubo* u, uint32_t par
     size_t npx = (size_t)W * H;
     for (size_t i = 0; i < npx; ++i) vis[i] = RDR_VIS_CLEAR;
     uint64_t draws_visible = 0, meshlets_tested = 0, meshlets_visible = 0, tris_submitted = 0;
-    uint64_t tris_tested = 0, tris_raster = 0, tris_big = 0, fragments = 0;
+    uint64_t tris_tested = 0, tris_raster = 0, tris_big = 0, fragments = 0, vertices = 0;
 
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : draws_visible, meshlets_tested, \
-    meshlets_visible, tris_submitted, tris_tested, tris_raster, tris_big, fragments)
+    meshlets_visible, tris_submitted, tris_tested, tris_raster, tris_big, fragments, vertices)
     for (int64_t di = 0; di < (int64_t)s->draw_count; ++di) {
         uint32_t lod = 0;
         int visible = 0;
@@ -462,7 +463,7 @@ int orc_render_visbuffer(const rdr_scene_desc* s, const rdr_ubo* u, uint32_t par
         float max_scale = model_max_scale(model);
         alpha_test at;
         make_alpha_test(s, d, &at);
-        geo_ctx c = {s, u, W, H, vis, 0, 0, 0, 0};
+        geo_ctx c = {s, u, W, H, vis, 0, 0, 0, 0, 0};
         for (uint32_t k = 0; k < L->meshlet_count; ++k) {
             uint32_t instance = d->meshlet_visibility_offset + k;
             if (instance < part_lo || instance >= part_hi) continue;
@@ -474,7 +475,7 @@ int orc_render_visbuffer(const rdr_scene_desc* s, const rdr_ubo* u, uint32_t par
             draw_meshlet(&c, (uint32_t)di, mi, instance, &at);
         }
         tris_tested += c.tris_tested; tris_raster += c.tris_raster;
-        tris_big += c.tris_big; fragments += c.fragments;
+        tris_big += c.tris_big; fragments += c.fragments; vertices += c.vertices;
     }
     if (stats) {
         memset(stats, 0, sizeof(*stats));
@@ -486,6 +487,7 @@ int orc_render_visbuffer(const rdr_scene_desc* s, const rdr_ubo* u, uint32_t par
         stats->triangles_rasterised = tris_raster;
         stats->triangles_big = tris_big;
         stats->fragments = fragments;
+        stats->vertices_transformed = vertices;
     }
     return 0;
 }

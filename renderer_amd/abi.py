@@ -187,6 +187,8 @@ class Stats(C.Structure):
         ("triangles_big", C.c_uint64),
         ("fragments", C.c_uint64),
         ("pixels_covered", C.c_uint64),
+        ("vertices_transformed", C.c_uint64),
+        ("frames_timed", C.c_uint64),
     ]
 
     def as_dict(self):

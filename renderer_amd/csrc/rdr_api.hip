@@ -57,8 +57,12 @@ struct rdr_renderer {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t events[8]{};
-    bool has_events = false;
+    // time_kernels: a ring of per-frame event sets so that timing never forces a host sync
+    static constexpr int kRing = 64;
+    std::vector<hipEvent_t> ring; // kRing * 8
+    bool slot_geometry[kRing]{}, slot_shade[kRing]{};
+    uint64_t frames_started = 0; // frames since the last rdr_get_stats
+    int cur_slot = 0;
     bool frame_rendered = false;
 
     // frame resources
@@ -337,8 +341,10 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
     RDR_HIP(hipSetDevice(r->device));
     RDR_HIP(hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking));
     r->stream = r->own_stream;
-    for (auto& e : r->events) RDR_HIP(hipEventCreate(&e));
-    r->has_events = true;
+    if (r->cfg.time_kernels) {
+        r->ring.resize((size_t)rdr_renderer::kRing * 8);
+        for (auto& e : r->ring) RDR_HIP(hipEventCreate(&e));
+    }
     const size_t npx = (size_t)width * height;
     if (r->vis.alloc(npx) || r->color.alloc(npx * 4) || r->counters.alloc(1)) return 1;
     RDR_HIP(hipMemset(r->counters.ptr, 0, sizeof(FrameCounters)));
@@ -356,8 +362,7 @@ void rdr_destroy(rdr_renderer* r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
     (void)hipStreamSynchronize(r->stream);
-    if (r->has_events)
-        for (auto& e : r->events) (void)hipEventDestroy(e);
+    for (auto& e : r->ring) (void)hipEventDestroy(e);
     if (r->own_stream) (void)hipStreamDestroy(r->own_stream);
     delete r;
 }
@@ -521,7 +526,15 @@ int rdr_render_visbuffer(rdr_renderer* r, const float cam_pos[3], const float ca
     RDR_HIP(hipSetDevice(r->device));
     build_ubo(r->width, r->height, cam_pos, cam_dir, sun_dir, r->sv.draw_count, r->cfg.lod_enabled, r->cfg.cull_enabled, &r->ubo);
     const FrameView fv = make_frame_view(r);
-    if (rdr_launch_geometry(r->sv, fv, r->stream, r->cfg.time_kernels ? r->events : nullptr)) return 1;
+    hipEvent_t* ev = nullptr;
+    if (r->cfg.time_kernels) {
+        r->cur_slot = (int)(r->frames_started % rdr_renderer::kRing);
+        r->frames_started++;
+        r->slot_geometry[r->cur_slot] = true;
+        r->slot_shade[r->cur_slot] = false;
+        ev = r->ring.data() + (size_t)r->cur_slot * 8;
+    }
+    if (rdr_launch_geometry(r->sv, fv, r->stream, ev)) return 1;
     r->frame_rendered = true;
     return 0;
 }
@@ -531,9 +544,13 @@ int rdr_shade(rdr_renderer* r) {
     RDR_CHECK(r->has_scene && r->frame_rendered, "rdr_shade: no visibility buffer rendered yet");
     RDR_HIP(hipSetDevice(r->device));
     const FrameView fv = make_frame_view(r);
-    if (r->cfg.time_kernels) RDR_HIP(hipEventRecord(r->events[6], r->stream));
+    hipEvent_t* ev = r->cfg.time_kernels ? r->ring.data() + (size_t)r->cur_slot * 8 : nullptr;
+    if (ev) RDR_HIP(hipEventRecord(ev[6], r->stream));
     if (rdr_launch_shade(r->sv, fv, r->stream)) return 1;
-    if (r->cfg.time_kernels) RDR_HIP(hipEventRecord(r->events[7], r->stream));
+    if (ev) {
+        RDR_HIP(hipEventRecord(ev[7], r->stream));
+        r->slot_shade[r->cur_slot] = true;
+    }
     return 0;
 }
 
@@ -596,17 +613,37 @@ int rdr_get_stats(rdr_renderer* r, rdr_stats* out) {
     st.triangles_big = fc.triangles_big;
     st.fragments = fc.fragments;
     st.pixels_covered = fc.pixels_covered;
-    if (r->cfg.time_kernels && r->frame_rendered) {
-        // events 0..5 bracket clear, draw cull, meshlet cull, raster, deferred; 6..7 bracket shading
+    if (r->cfg.time_kernels && r->frames_started) {
+        // events 0..5 bracket clear, draw cull, meshlet cull, raster, deferred; 6..7 bracket shading.
+        // Mean over the frames still in the ring (the stream was synchronised above).
         const int map[5] = {RDR_K_CLEAR, RDR_K_DRAW_CULL, RDR_K_MESHLET_CULL, RDR_K_RASTER, RDR_K_BIG_RASTER};
-        for (int i = 0; i < 5; ++i) {
-            float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, r->events[i], r->events[i + 1]) == hipSuccess) st.kernel_ms[map[i]] = ms;
+        const int n = (int)std::min<uint64_t>(r->frames_started, rdr_renderer::kRing);
+        double sum[RDR_STAT_KERNELS] = {0};
+        int n_geo = 0, n_shade = 0;
+        for (int f = 0; f < n; ++f) {
+            hipEvent_t* ev = r->ring.data() + (size_t)f * 8;
+            if (r->slot_geometry[f]) {
+                bool ok = true;
+                float ms[5];
+                for (int i = 0; i < 5 && ok; ++i) ok = hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]) == hipSuccess;
+                if (ok) {
+                    for (int i = 0; i < 5; ++i) sum[map[i]] += ms[i];
+                    n_geo++;
+                }
+            }
+            if (r->slot_shade[f]) {
+                float ms = 0.0f;
+                if (hipEventElapsedTime(&ms, ev[6], ev[7]) == hipSuccess) { sum[RDR_K_SHADE] += ms; n_shade++; }
+            }
+            r->slot_geometry[f] = r->slot_shade[f] = false;
         }
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, r->events[6], r->events[7]) == hipSuccess) st.kernel_ms[RDR_K_SHADE] = ms;
         (void)hipGetLastError();
+        for (int i = 0; i < 5; ++i) if (n_geo) st.kernel_ms[map[i]] = (float)(sum[map[i]] / n_geo);
+        if (n_shade) st.kernel_ms[RDR_K_SHADE] = (float)(sum[RDR_K_SHADE] / n_shade);
+        st.frames_timed = (uint64_t)n_geo;
+        r->frames_started = 0;
     }
+    st.vertices_transformed = fc.vertices_transformed;
     *out = st;
     return 0;
 }

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
     const uint32_t vis_count = min(fv.counters->vis_count, fv.visible_capacity);
     const float half_w = (float)fv.width * 0.5f, half_h = (float)fv.height * 0.5f;
 
-    uint32_t st_tested = 0, st_raster = 0, st_big = 0, st_frags = 0;
+    uint32_t st_tested = 0, st_raster = 0, st_big = 0, st_frags = 0, st_verts = 0;
     for (uint32_t mi = blockIdx.x; mi < vis_count; mi += gridDim.x) {
         const VisibleMeshlet vm = fv.visible[mi];
         const rdr_mesh_draw d = sv.draws[vm.draw_id];
@@ -392,6 +392,7 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
 
         __syncthreads(); // previous meshlet's readers are done
         if (lane < m.vertex_count) {
+            st_verts++;
             const uint32_t vi = sv.meshlet_vertices[m.vertex_offset + lane] + mesh_vertex_offset;
             const vec4 world = mul_m4(model, mk4(sv.pos_x[vi], sv.pos_y[vi], sv.pos_z[vi], 1.0f));
             const vec4 clip = mul_m4(u.view_proj, world);
@@ -535,7 +536,9 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
     }
     if (fv.collect_stats) {
         const uint32_t a = wave_sum(st_tested), b = wave_sum(st_raster), c = wave_sum(st_big), f = wave_sum(st_frags);
+        const uint32_t v = wave_sum(st_verts);
         if (lane == 0) {
+            if (v) atomicAdd(&fv.counters->vertices_transformed, (unsigned long long)v);
             if (a) atomicAdd(&fv.counters->triangles_tested, (unsigned long long)a);
             if (b) atomicAdd(&fv.counters->triangles_rasterised, (unsigned long long)b);
             if (c) atomicAdd(&fv.counters->triangles_big, (unsigned long long)c);

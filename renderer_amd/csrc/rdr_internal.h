@@ -75,7 +75,8 @@ struct FrameCounters {
     unsigned long long triangles_big;
     unsigned long long fragments;
     unsigned long long pixels_covered;
-    unsigned long long _pad1[7];
+    unsigned long long vertices_transformed;
+    unsigned long long _pad1[6];
 };
 static_assert(sizeof(FrameCounters) == 192, "FrameCounters layout");
 

@@ -170,7 +170,7 @@ def test_render_is_idempotent():
 def test_errors():
     g = Renderer(64, 36)
     with pytest.raises(RendererError, match="no scene"):
-        g.render()
+        g.render(Camera((0, 0, 0), (0, 0, -1)), (0, 1, 0))
     sc = synth.make_field(2, 1, with_env=False)
     bad = synth.make_field(2, 1, with_env=False)
     bad.mesh_draws["mesh_index"] = 7
