@@ -36,7 +36,9 @@ def algorithmic_bytes(st, width, height, draws):
         "meshlet_cull": st["commands"] * 32 + st["meshlets_tested"] * 32 + st["meshlets_visible"] * 16,
         "raster": st["meshlets_visible"] * (16 + 32) + st["vertices_transformed"] * (4 + 12)
                   + st["triangles_tested"] * 3 + st["fragments"] * 8,
-        "shade": px * 8 + st["pixels_covered"] * (15 + 3 * 64) + px * 4,
+        # shadow pass: key + 3 positions per covered pixel + 1 B mask; BVH nodes are shared (L2)
+        "shadow": px * 8 + st["pixels_covered"] * (15 + 3 * 12) + px * 1,
+        "shade": px * 8 + px * 1 + st["pixels_covered"] * (15 + 3 * 64) + px * 4,
     }
 
 
@@ -146,7 +148,7 @@ def main():
         fps = args.steps / elapsed
         kms = st["kernel_ms"]
         ab = algorithmic_bytes(st, W, H, len(scene.mesh_draws))
-        dom = max(("raster", "shade", "meshlet_cull", "clear", "draw_cull"), key=lambda k: kms[k])
+        dom = max(("raster", "shade", "shadow", "meshlet_cull", "clear", "draw_cull"), key=lambda k: kms[k])
         if dom == "raster":
             ab_dom, t_dom = ab["raster"], kms["raster"]
         else:

@@ -230,7 +230,7 @@ enum {
     RDR_K_DRAW_CULL = 1,
     RDR_K_MESHLET_CULL = 2,
     RDR_K_RASTER = 3,
-    RDR_K_CLIP_SETUP = 4,
+    RDR_K_SHADOW = 4,
     RDR_K_BIG_RASTER = 5,
     RDR_K_SHADE = 6,
     RDR_K_RESOLVE = 7

@@ -59,11 +59,12 @@ struct rdr_renderer {
     hipStream_t stream = nullptr;
     // time_kernels: a ring of per-frame event sets so that timing never forces a host sync
     static constexpr int kRing = 64;
-    std::vector<hipEvent_t> ring; // kRing * 8
+    static constexpr int kEvents = 9;
+    std::vector<hipEvent_t> ring; // kRing * kEvents
     bool slot_geometry[kRing]{}, slot_shade[kRing]{};
     uint64_t frames_started = 0; // frames since the last rdr_get_stats
     int cur_slot = 0;
-    bool frame_rendered = false;
+    bool frame_rendered = false, shaded = false;
 
     // frame resources
     DeviceBuffer<unsigned long long> vis;
@@ -74,6 +75,8 @@ struct rdr_renderer {
     DeviceBuffer<DeferredTriangle> deferred;
     DeviceBuffer<uint32_t> resolve_out;
     DeviceBuffer<float> srgb_lut;
+    DeviceBuffer<uint8_t> shadow;
+    DeviceBuffer<uint32_t> stat_slots;
 
     // scene resources
     DeviceBuffer<rdr_vertex> vertices;
@@ -304,6 +307,21 @@ FrameView make_frame_view(rdr_renderer* r) {
     fv.visible_capacity = (uint32_t)r->visible.count;
     fv.deferred_capacity = (uint32_t)r->deferred.count;
     fv.collect_stats = r->cfg.collect_stats;
+    fv.shadow = r->shadow.ptr;
+    fv.stat_slots = r->stat_slots.ptr;
+    GridPlan& g = fv.grid;
+    g.draw_blocks = std::max(1u, (r->sv.draw_count + 255u) / 256u);
+    g.cull_blocks = std::max(1u, std::min((fv.command_capacity + 15u) / 16u, 1024u));
+    g.raster_blocks = std::max(1u, std::min(fv.visible_capacity, 256u * 32u));
+    g.deferred_blocks = 2048;
+    g.shade_blocks_x = (r->width + 15u) / 16u;
+    g.shade_blocks_y = (fv.row_hi - fv.row_lo + 15u) / 16u;
+    g.slot_draw = 0;
+    g.slot_cull = g.slot_draw + g.draw_blocks;
+    g.slot_raster = g.slot_cull + g.cull_blocks * kCullSlots;
+    g.slot_deferred = g.slot_raster + g.raster_blocks * kRasterSlots;
+    g.slot_shade = g.slot_deferred + g.deferred_blocks;
+    g.slot_total = g.slot_shade + g.shade_blocks_x * ((r->height + 15u) / 16u);
     return fv;
 }
 
@@ -342,11 +360,11 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
     RDR_HIP(hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking));
     r->stream = r->own_stream;
     if (r->cfg.time_kernels) {
-        r->ring.resize((size_t)rdr_renderer::kRing * 8);
+        r->ring.resize((size_t)rdr_renderer::kRing * rdr_renderer::kEvents);
         for (auto& e : r->ring) RDR_HIP(hipEventCreate(&e));
     }
     const size_t npx = (size_t)width * height;
-    if (r->vis.alloc(npx) || r->color.alloc(npx * 4) || r->counters.alloc(1)) return 1;
+    if (r->vis.alloc(npx) || r->color.alloc(npx * 4) || r->counters.alloc(1) || r->shadow.alloc(npx)) return 1;
     RDR_HIP(hipMemset(r->counters.ptr, 0, sizeof(FrameCounters)));
     float lut[256];
     for (int i = 0; i < 256; ++i) {
@@ -429,6 +447,16 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
     }
     if (r->commands.alloc(cmd_cap) || r->visible.alloc(vis_cap)) return 1;
     if (r->deferred.alloc((size_t)std::min<uint64_t>(std::max<uint64_t>(tri_total, 1u << 16), 1u << 20))) return 1;
+    {
+        // statistics slots for the largest launch geometry this scene can produce
+        r->sv.draw_count = s.draw_count;
+        const uint32_t keep_lo = r->row_lo, keep_hi = r->row_hi;
+        r->row_lo = 0; r->row_hi = r->height;
+        const FrameView fv = make_frame_view(r);
+        r->row_lo = keep_lo; r->row_hi = keep_hi;
+        if (r->stat_slots.alloc(fv.grid.slot_total)) return 1;
+        RDR_HIP(hipMemset(r->stat_slots.ptr, 0, (size_t)fv.grid.slot_total * 4));
+    }
 
     // textures and environment
     {
@@ -532,10 +560,11 @@ int rdr_render_visbuffer(rdr_renderer* r, const float cam_pos[3], const float ca
         r->frames_started++;
         r->slot_geometry[r->cur_slot] = true;
         r->slot_shade[r->cur_slot] = false;
-        ev = r->ring.data() + (size_t)r->cur_slot * 8;
+        ev = r->ring.data() + (size_t)r->cur_slot * rdr_renderer::kEvents;
     }
     if (rdr_launch_geometry(r->sv, fv, r->stream, ev)) return 1;
     r->frame_rendered = true;
+    r->shaded = false;
     return 0;
 }
 
@@ -544,13 +573,10 @@ int rdr_shade(rdr_renderer* r) {
     RDR_CHECK(r->has_scene && r->frame_rendered, "rdr_shade: no visibility buffer rendered yet");
     RDR_HIP(hipSetDevice(r->device));
     const FrameView fv = make_frame_view(r);
-    hipEvent_t* ev = r->cfg.time_kernels ? r->ring.data() + (size_t)r->cur_slot * 8 : nullptr;
-    if (ev) RDR_HIP(hipEventRecord(ev[6], r->stream));
-    if (rdr_launch_shade(r->sv, fv, r->stream)) return 1;
-    if (ev) {
-        RDR_HIP(hipEventRecord(ev[7], r->stream));
-        r->slot_shade[r->cur_slot] = true;
-    }
+    hipEvent_t* ev = r->cfg.time_kernels ? r->ring.data() + (size_t)r->cur_slot * rdr_renderer::kEvents : nullptr;
+    if (rdr_launch_shade(r->sv, fv, r->stream, ev)) return 1;
+    r->shaded = true;
+    if (ev) r->slot_shade[r->cur_slot] = true;
     return 0;
 }
 
@@ -603,25 +629,36 @@ int rdr_get_stats(rdr_renderer* r, rdr_stats* out) {
     FrameCounters fc;
     if (fetch_counters(r, &fc)) return 1;
     rdr_stats st{};
-    st.draws_visible = fc.draws_visible;
     st.commands = fc.cmd_count;
-    st.meshlets_tested = fc.meshlets_tested;
-    st.meshlets_visible = fc.meshlets_visible;
-    st.triangles_submitted = fc.triangles_submitted;
-    st.triangles_tested = fc.triangles_tested;
-    st.triangles_rasterised = fc.triangles_rasterised;
-    st.triangles_big = fc.triangles_big;
-    st.fragments = fc.fragments;
-    st.pixels_covered = fc.pixels_covered;
+    if (r->cfg.collect_stats && r->frame_rendered) {
+        // sum the per-workgroup slots of the last frame
+        const FrameView fv = make_frame_view(r);
+        const GridPlan& g = fv.grid;
+        std::vector<uint32_t> slots(g.slot_total);
+        RDR_HIP(hipMemcpy(slots.data(), r->stat_slots.ptr, (size_t)g.slot_total * 4, hipMemcpyDeviceToHost));
+        for (uint32_t b = 0; b < g.draw_blocks; ++b) st.draws_visible += slots[g.slot_draw + b];
+        for (uint32_t b = 0; b < g.cull_blocks; ++b) {
+            const uint32_t* p = &slots[g.slot_cull + b * kCullSlots];
+            st.meshlets_tested += p[0]; st.meshlets_visible += p[1]; st.triangles_submitted += p[2];
+        }
+        for (uint32_t b = 0; b < g.raster_blocks; ++b) {
+            const uint32_t* p = &slots[g.slot_raster + b * kRasterSlots];
+            st.triangles_tested += p[0]; st.triangles_rasterised += p[1]; st.triangles_big += p[2];
+            st.fragments += p[3]; st.vertices_transformed += p[4];
+        }
+        for (uint32_t b = 0; b < g.deferred_blocks; ++b) st.fragments += slots[g.slot_deferred + b];
+        if (r->shaded)
+            for (uint32_t b = 0; b < g.shade_blocks_x * g.shade_blocks_y; ++b) st.pixels_covered += slots[g.slot_shade + b];
+    }
     if (r->cfg.time_kernels && r->frames_started) {
-        // events 0..5 bracket clear, draw cull, meshlet cull, raster, deferred; 6..7 bracket shading.
+        // events 0..5 bracket clear, draw cull, meshlet cull, raster, deferred; 6..8 bracket shadow and shading.
         // Mean over the frames still in the ring (the stream was synchronised above).
         const int map[5] = {RDR_K_CLEAR, RDR_K_DRAW_CULL, RDR_K_MESHLET_CULL, RDR_K_RASTER, RDR_K_BIG_RASTER};
         const int n = (int)std::min<uint64_t>(r->frames_started, rdr_renderer::kRing);
         double sum[RDR_STAT_KERNELS] = {0};
         int n_geo = 0, n_shade = 0;
         for (int f = 0; f < n; ++f) {
-            hipEvent_t* ev = r->ring.data() + (size_t)f * 8;
+            hipEvent_t* ev = r->ring.data() + (size_t)f * rdr_renderer::kEvents;
             if (r->slot_geometry[f]) {
                 bool ok = true;
                 float ms[5];
@@ -632,18 +669,22 @@ int rdr_get_stats(rdr_renderer* r, rdr_stats* out) {
                 }
             }
             if (r->slot_shade[f]) {
-                float ms = 0.0f;
-                if (hipEventElapsedTime(&ms, ev[6], ev[7]) == hipSuccess) { sum[RDR_K_SHADE] += ms; n_shade++; }
+                float ms0 = 0.0f, ms1 = 0.0f;
+                if (hipEventElapsedTime(&ms0, ev[6], ev[7]) == hipSuccess && hipEventElapsedTime(&ms1, ev[7], ev[8]) == hipSuccess) {
+                    sum[RDR_K_SHADOW] += ms0; sum[RDR_K_SHADE] += ms1; n_shade++;
+                }
             }
             r->slot_geometry[f] = r->slot_shade[f] = false;
         }
         (void)hipGetLastError();
         for (int i = 0; i < 5; ++i) if (n_geo) st.kernel_ms[map[i]] = (float)(sum[map[i]] / n_geo);
-        if (n_shade) st.kernel_ms[RDR_K_SHADE] = (float)(sum[RDR_K_SHADE] / n_shade);
+        if (n_shade) {
+            st.kernel_ms[RDR_K_SHADE] = (float)(sum[RDR_K_SHADE] / n_shade);
+            st.kernel_ms[RDR_K_SHADOW] = (float)(sum[RDR_K_SHADOW] / n_shade);
+        }
         st.frames_timed = (uint64_t)n_geo;
         r->frames_started = 0;
     }
-    st.vertices_transformed = fc.vertices_transformed;
     *out = st;
     return 0;
 }

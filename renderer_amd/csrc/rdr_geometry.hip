@@ -94,57 +94,72 @@ __global__ __launch_bounds__(256) void k_draw_cull(SceneView sv, FrameView fv) {
         fv.commands[slot] = cmd;
     }
     if (fv.collect_stats) {
+        __shared__ uint32_t wg_emitted[4];
         const uint32_t n = wave_sum(emitted ? 1u : 0u);
-        if (lane == 0 && n) atomicAdd(&fv.counters->draws_visible, (unsigned long long)n);
+        if (lane == 0) wg_emitted[threadIdx.x >> 6] = n;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            fv.stat_slots[fv.grid.slot_draw + blockIdx.x] = wg_emitted[0] + wg_emitted[1] + wg_emitted[2] + wg_emitted[3];
     }
 }
 
 // ------------------------------------------------------------------------------
-// Meshlet cull: one wave per command, one lane per meshlet.
+// Meshlet cull: one wave per command, one lane per meshlet; the 16 waves of a
+// workgroup reserve their output slots with a single atomic.
 // ------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_meshlet_cull(SceneView sv, FrameView fv) {
+__global__ __launch_bounds__(1024) void k_meshlet_cull(SceneView sv, FrameView fv) {
+    __shared__ uint32_t wave_count[16];
+    __shared__ uint32_t wg_base;
     const uint32_t lane = lane_id();
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t wave = threadIdx.x >> 6;
     const rdr_ubo& u = fv.ubo;
     const uint32_t cmd_count = min(fv.counters->cmd_count, fv.command_capacity);
 
-    unsigned long long st_tested = 0, st_visible = 0, st_tris = 0;
-    for (uint32_t ci = wave; ci < cmd_count; ci += n_waves) {
-        const CullCommand* cp = &fv.commands[__builtin_amdgcn_readfirstlane(ci)];
-        const uint32_t draw_id = cp->draw_id, first = cp->meshlet_first, count = cp->count;
-        const uint32_t instance_first = cp->instance_first;
-        const float max_scale = cp->max_scale;
-        const uint32_t model_index = sv.draws[draw_id].model_index;
-        float model[16];
-        load_m4(sv.transforms + (size_t)model_index * 16, model);
-
-        bool accept = lane < count;
-        uint32_t tri_count = 0;
-        if (accept) {
-            const rdr_meshlet m = sv.meshlets[first + lane];
-            tri_count = m.triangle_count;
-            const vec4 cw = mul_m4(model, mk4(m.center[0], m.center[1], m.center[2], 1.0f));
-            const vec4 cv = mul_m4(u.view, cw);
-            const vec3 cc = mk3(cv.x, cv.y, cv.z);
-            const vec4 aw = mul_m4(model, mk4((float)m.cone_axis[0] / 127.0f, (float)m.cone_axis[1] / 127.0f,
-                                              (float)m.cone_axis[2] / 127.0f, 0.0f));
-            const vec4 av = mul_m4(u.view, aw);
-            const vec3 axis = normalize3(mk3(av.x, av.y, av.z));
-            const float radius = max_scale * m.radius;
-            const float cutoff = (float)m.cone_cutoff / 127.0f;
-            accept = accept && !(dot3(cc, axis) >= cutoff * len3(cc) + radius);
-            accept = accept && (cc.z * -u.frustum[1] + cc.x * u.frustum[0] < radius);
-            accept = accept && (cc.z * -u.frustum[3] + cc.y * u.frustum[2] < radius);
-            accept = accept && (cc.z + radius > -u.near_plane) && (cc.z + radius < u.far_plane);
+    uint32_t st_tested = 0, st_visible = 0, st_tris = 0;
+    for (uint32_t c0 = blockIdx.x * 16u; c0 < cmd_count; c0 += gridDim.x * 16u) {
+        const uint32_t ci = c0 + wave;
+        bool accept = false;
+        uint32_t draw_id = 0, first = 0, instance_first = 0, tri_count = 0, count = 0;
+        if (ci < cmd_count) {
+            const CullCommand* cp = &fv.commands[__builtin_amdgcn_readfirstlane(ci)];
+            draw_id = cp->draw_id; first = cp->meshlet_first; count = cp->count;
+            instance_first = cp->instance_first;
+            const float max_scale = cp->max_scale;
+            const uint32_t model_index = sv.draws[draw_id].model_index;
+            float model[16];
+            load_m4(sv.transforms + (size_t)model_index * 16, model);
+            accept = lane < count;
+            if (accept) {
+                const rdr_meshlet m = sv.meshlets[first + lane];
+                tri_count = m.triangle_count;
+                const vec4 cw = mul_m4(model, mk4(m.center[0], m.center[1], m.center[2], 1.0f));
+                const vec4 cv = mul_m4(u.view, cw);
+                const vec3 cc = mk3(cv.x, cv.y, cv.z);
+                const vec4 aw = mul_m4(model, mk4((float)m.cone_axis[0] / 127.0f, (float)m.cone_axis[1] / 127.0f,
+                                                  (float)m.cone_axis[2] / 127.0f, 0.0f));
+                const vec4 av = mul_m4(u.view, aw);
+                const vec3 axis = normalize3(mk3(av.x, av.y, av.z));
+                const float radius = max_scale * m.radius;
+                const float cutoff = (float)m.cone_cutoff / 127.0f;
+                accept = accept && !(dot3(cc, axis) >= cutoff * len3(cc) + radius);
+                accept = accept && (cc.z * -u.frustum[1] + cc.x * u.frustum[0] < radius);
+                accept = accept && (cc.z * -u.frustum[3] + cc.y * u.frustum[2] < radius);
+                accept = accept && (cc.z + radius > -u.near_plane) && (cc.z + radius < u.far_plane);
+            }
         }
         const unsigned long long mask = __ballot(accept);
         const uint32_t n_acc = (uint32_t)__popcll(mask);
-        uint32_t base = 0;
-        if (lane == 0 && n_acc) base = atomicAdd(&fv.counters->vis_count, n_acc);
-        base = __shfl(base, 0, 64);
+        if (lane == 0) wave_count[wave] = n_acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
+            for (int w = 0; w < 16; ++w) total += wave_count[w];
+            wg_base = total ? atomicAdd(&fv.counters->vis_count, total) : 0u;
+        }
+        __syncthreads();
         if (accept) {
-            const uint32_t slot = base + ballot_rank(mask);
+            uint32_t slot = wg_base + ballot_rank(mask);
+            for (uint32_t w = 0; w < wave; ++w) slot += wave_count[w];
             if (slot < fv.visible_capacity) {
                 VisibleMeshlet v;
                 v.draw_id = draw_id;
@@ -154,17 +169,23 @@ __global__ __launch_bounds__(256) void k_meshlet_cull(SceneView sv, FrameView fv
                 fv.visible[slot] = v;
             }
         }
-        st_tested += count;
-        st_visible += n_acc;
+        __syncthreads(); // wave_count is rewritten next iteration
+        st_tested += lane == 0 ? count : 0u;
+        st_visible += lane == 0 ? n_acc : 0u;
         st_tris += tri_count;
     }
     if (fv.collect_stats) {
-        const unsigned long long t = wave_sum64(st_tris);
+        __shared__ uint32_t wg_stats[3];
+        if (threadIdx.x < 3) wg_stats[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t a = wave_sum(st_tested), b = wave_sum(st_visible), c = wave_sum(st_tris);
         if (lane == 0) {
-            if (st_tested) atomicAdd(&fv.counters->meshlets_tested, st_tested);
-            if (st_visible) atomicAdd(&fv.counters->meshlets_visible, st_visible);
-            if (t) atomicAdd(&fv.counters->triangles_submitted, t);
+            atomicAdd(&wg_stats[0], a);
+            atomicAdd(&wg_stats[1], b);
+            atomicAdd(&wg_stats[2], c);
         }
+        __syncthreads();
+        if (threadIdx.x < 3) fv.stat_slots[fv.grid.slot_cull + blockIdx.x * kCullSlots + threadIdx.x] = wg_stats[threadIdx.x];
     }
 }
 
@@ -538,11 +559,8 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
         const uint32_t a = wave_sum(st_tested), b = wave_sum(st_raster), c = wave_sum(st_big), f = wave_sum(st_frags);
         const uint32_t v = wave_sum(st_verts);
         if (lane == 0) {
-            if (v) atomicAdd(&fv.counters->vertices_transformed, (unsigned long long)v);
-            if (a) atomicAdd(&fv.counters->triangles_tested, (unsigned long long)a);
-            if (b) atomicAdd(&fv.counters->triangles_rasterised, (unsigned long long)b);
-            if (c) atomicAdd(&fv.counters->triangles_big, (unsigned long long)c);
-            if (f) atomicAdd(&fv.counters->fragments, (unsigned long long)f);
+            uint32_t* slot = fv.stat_slots + fv.grid.slot_raster + blockIdx.x * kRasterSlots;
+            slot[0] = a; slot[1] = b; slot[2] = c; slot[3] = f; slot[4] = v;
         }
     }
 }
@@ -643,7 +661,7 @@ __global__ __launch_bounds__(64) void k_deferred(SceneView sv, FrameView fv) {
     }
     if (fv.collect_stats) {
         const uint32_t f = wave_sum(st_frags);
-        if (lane == 0 && f) atomicAdd(&fv.counters->fragments, (unsigned long long)f);
+        if (lane == 0) fv.stat_slots[fv.grid.slot_deferred + blockIdx.x] = f;
     }
 }
 
@@ -684,16 +702,14 @@ int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t st
     hipLaunchKernelGGL(k_clear, dim3(clear_blocks), dim3(256), 0, stream, fv.vis, npx, fv.counters);
     if (ev) RDR_HIP(hipEventRecord(ev[1], stream));
     if (sv.draw_count) {
-        hipLaunchKernelGGL(k_draw_cull, dim3((sv.draw_count + 255) / 256), dim3(256), 0, stream, sv, fv);
+        hipLaunchKernelGGL(k_draw_cull, dim3(fv.grid.draw_blocks), dim3(256), 0, stream, sv, fv);
         if (ev) RDR_HIP(hipEventRecord(ev[2], stream));
         // persistent grids: the work-list lengths live in device memory
-        const uint32_t cull_blocks = max(1u, min((fv.command_capacity + 3) / 4, 2048u));
-        hipLaunchKernelGGL(k_meshlet_cull, dim3(cull_blocks), dim3(256), 0, stream, sv, fv);
+        hipLaunchKernelGGL(k_meshlet_cull, dim3(fv.grid.cull_blocks), dim3(1024), 0, stream, sv, fv);
         if (ev) RDR_HIP(hipEventRecord(ev[3], stream));
-        const uint32_t raster_blocks = max(1u, min(fv.visible_capacity, 256u * 32u));
-        hipLaunchKernelGGL(k_raster, dim3(raster_blocks), dim3(64), 0, stream, sv, fv);
+        hipLaunchKernelGGL(k_raster, dim3(fv.grid.raster_blocks), dim3(64), 0, stream, sv, fv);
         if (ev) RDR_HIP(hipEventRecord(ev[4], stream));
-        hipLaunchKernelGGL(k_deferred, dim3(2048), dim3(64), 0, stream, sv, fv);
+        hipLaunchKernelGGL(k_deferred, dim3(fv.grid.deferred_blocks), dim3(64), 0, stream, sv, fv);
         if (ev) RDR_HIP(hipEventRecord(ev[5], stream));
     }
     RDR_HIP(hipGetLastError());

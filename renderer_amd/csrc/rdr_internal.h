@@ -59,24 +59,14 @@ struct DeferredTriangle {
 };
 static_assert(sizeof(DeferredTriangle) == 112, "DeferredTriangle layout");
 
-// Frame counters, one cache line apart from the work-list heads.
+// Heads of the per-frame work lists.
 struct FrameCounters {
     uint32_t cmd_count;
     uint32_t vis_count;
     uint32_t deferred_count;
     uint32_t deferred_overflow;
     uint32_t _pad0[12];
-    unsigned long long draws_visible;
-    unsigned long long meshlets_tested;
-    unsigned long long meshlets_visible;
-    unsigned long long triangles_submitted;
-    unsigned long long triangles_tested;
-    unsigned long long triangles_rasterised;
-    unsigned long long triangles_big;
-    unsigned long long fragments;
-    unsigned long long pixels_covered;
-    unsigned long long vertices_transformed;
-    unsigned long long _pad1[6];
+    unsigned long long _pad1[16];
 };
 static_assert(sizeof(FrameCounters) == 192, "FrameCounters layout");
 
@@ -141,6 +131,13 @@ struct SceneView {
     GpuCubemap lambertian, ggx, charlie;
 };
 
+// Launch geometry of one frame and where each kernel's workgroups put their statistics.
+struct GridPlan {
+    uint32_t draw_blocks, cull_blocks, raster_blocks, deferred_blocks, shade_blocks_x, shade_blocks_y;
+    uint32_t slot_draw, slot_cull, slot_raster, slot_deferred, slot_shade, slot_total;
+};
+constexpr uint32_t kCullSlots = 4, kRasterSlots = 8;
+
 struct FrameView {
     rdr_ubo ubo;
     unsigned long long* vis;
@@ -154,6 +151,11 @@ struct FrameView {
     uint32_t row_lo, row_hi;
     uint32_t command_capacity, visible_capacity, deferred_capacity;
     uint32_t collect_stats;
+    uint8_t* shadow; // one byte per pixel: 1 = the sun ray is blocked
+    // Per-workgroup statistics: every workgroup stores its partial counts in its own
+    // slot with plain stores (no contended atomics); the host sums the slots on request.
+    uint32_t* stat_slots;
+    GridPlan grid;
 };
 
 // ---- host BVH builder (rdr_bvh.cpp) -----------------------------------------
@@ -170,7 +172,6 @@ void rdr_build_blas(const rdr_scene_desc& s, HostBvh& out);
 void rdr_build_tlas(const rdr_scene_desc& s, const float* transforms, HostBvh& io);
 
 // ---- kernel launchers (rdr_geometry.hip / rdr_shade.hip) ---------------------
-struct KernelTimers;
 int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev);
-int rdr_launch_shade(const SceneView& sv, const FrameView& fv, hipStream_t stream);
+int rdr_launch_shade(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev);
 int rdr_launch_resolve(const SceneView& sv, const FrameView& fv, uint32_t* out_xy, hipStream_t stream);

@@ -51,44 +51,70 @@ RDR_DEV bool ray_triangle(vec3 o, vec3 d, vec3 p0, vec3 p1, vec3 p2, float tmin,
     return t > tmin && t < tmax;
 }
 
-RDR_DEV bool blas_any_hit(const SceneView& sv, const GpuInstance& inst, vec3 o, vec3 d, float tmin, float tmax) {
+// Traversal stack: the first kLdsStack entries of each lane live in LDS (one
+// column per lane, so a wave's accesses are conflict-free), deeper entries spill
+// to a per-lane array.  The spill is never reached by reasonably balanced trees.
+constexpr int kLdsStack = 24;
+constexpr int kSpillStack = 40;
+
+struct TraversalStack {
+    uint32_t* lds; // &shared[lane], stride = block size
+    uint32_t stride;
+    uint32_t spill[kSpillStack];
+    int sp;
+    RDR_DEV void push(uint32_t v) {
+        if (sp < kLdsStack) lds[sp * stride] = v;
+        else if (sp < kLdsStack + kSpillStack) spill[sp - kLdsStack] = v;
+        ++sp;
+    }
+    RDR_DEV uint32_t pop() {
+        --sp;
+        return sp < kLdsStack ? lds[sp * stride] : spill[min(sp - kLdsStack, kSpillStack - 1)];
+    }
+};
+
+// Any-hit over one mesh's BLAS in object space.  Entries on the stack are node
+// indices relative to the mesh's root; `floor` is the stack height to stop at.
+RDR_DEV bool blas_any_hit(const SceneView& sv, const GpuInstance& inst, vec3 o, vec3 d, float tmin, float tmax,
+                          TraversalStack& st) {
     const vec3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    uint32_t stack[48];
-    int sp = 0;
-    stack[sp++] = inst.blas_root;
-    while (sp) {
-        const BvhNode n = sv.blas[stack[--sp]];
-        if (!ray_box(n, o, inv_d, tmin, tmax)) continue;
+    const BvhNode* nodes = sv.blas + inst.blas_root;
+    const int floor = st.sp;
+    if (!ray_box(nodes[0], o, inv_d, tmin, tmax)) return false;
+    st.push(0u);
+    while (st.sp > floor) {
+        const BvhNode n = nodes[st.pop()];
         if (n.count == 0) {
-            if (n.left != 0 && sp < 46) {
-                stack[sp++] = inst.blas_root + (uint32_t)n.left;
-                stack[sp++] = inst.blas_root + (uint32_t)n.left + 1u;
-            }
+            if (n.left == 0) continue; // empty mesh
+            const BvhNode l = nodes[n.left], r = nodes[n.left + 1];
+            if (ray_box(l, o, inv_d, tmin, tmax)) st.push((uint32_t)n.left);
+            if (ray_box(r, o, inv_d, tmin, tmax)) st.push((uint32_t)n.left + 1u);
             continue;
         }
         const float* tp = sv.blas_tris + ((size_t)inst.tri_base + (uint32_t)n.left) * 9;
         for (int i = 0; i < n.count; ++i, tp += 9) {
-            if (ray_triangle(o, d, mk3(tp[0], tp[1], tp[2]), mk3(tp[3], tp[4], tp[5]), mk3(tp[6], tp[7], tp[8]), tmin, tmax))
+            if (ray_triangle(o, d, mk3(tp[0], tp[1], tp[2]), mk3(tp[3], tp[4], tp[5]), mk3(tp[6], tp[7], tp[8]), tmin, tmax)) {
+                st.sp = floor;
                 return true;
+            }
         }
     }
     return false;
 }
 
-RDR_DEV bool shadow_any_hit(const SceneView& sv, vec3 o, vec3 d, float tmin, float tmax) {
+RDR_DEV bool shadow_any_hit(const SceneView& sv, vec3 o, vec3 d, float tmin, float tmax, TraversalStack& st) {
     if (sv.draw_count == 0) return false;
     const vec3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    uint32_t stack[48];
-    int sp = 0;
-    stack[sp++] = 0;
-    while (sp) {
-        const BvhNode n = sv.tlas[stack[--sp]];
-        if (!ray_box(n, o, inv_d, tmin, tmax)) continue;
+    st.sp = 0;
+    if (!ray_box(sv.tlas[0], o, inv_d, tmin, tmax)) return false;
+    st.push(0u);
+    while (st.sp > 0) {
+        const BvhNode n = sv.tlas[st.pop()];
         if (n.count == 0) {
-            if (n.left != 0 && sp < 46) {
-                stack[sp++] = (uint32_t)n.left;
-                stack[sp++] = (uint32_t)n.left + 1u;
-            }
+            if (n.left == 0) continue;
+            const BvhNode l = sv.tlas[n.left], r = sv.tlas[n.left + 1];
+            if (ray_box(l, o, inv_d, tmin, tmax)) st.push((uint32_t)n.left);
+            if (ray_box(r, o, inv_d, tmin, tmax)) st.push((uint32_t)n.left + 1u);
             continue;
         }
         for (int i = 0; i < n.count; ++i) {
@@ -99,7 +125,7 @@ RDR_DEV bool shadow_any_hit(const SceneView& sv, vec3 o, vec3 d, float tmin, flo
                                 ((iv[8] * o.x + iv[9] * o.y) + iv[10] * o.z) + iv[11]);
             const vec3 od = mk3((iv[0] * d.x + iv[1] * d.y) + iv[2] * d.z, (iv[4] * d.x + iv[5] * d.y) + iv[6] * d.z,
                                 (iv[8] * d.x + iv[9] * d.y) + iv[10] * d.z);
-            if (blas_any_hit(sv, inst, oo, od, tmin, tmax)) return true;
+            if (blas_any_hit(sv, inst, oo, od, tmin, tmax, st)) return true;
         }
     }
     return false;
@@ -288,8 +314,27 @@ RDR_DEV uint32_t srgb_encode(float c) {
 
 RDR_DEV vec3 vload3(const float* p) { return mk3(p[0], p[1], p[2]); }
 
+// World-space position of the surface point seen through a pixel (the shadow ray's origin).
+RDR_DEV vec3 pixel_world_position(const SceneView& sv, const rdr_ubo& u, uint32_t draw_id, uint32_t meshlet_index,
+                                  uint32_t tri, float uvx, float uvy) {
+    const rdr_mesh_draw d = sv.draws[draw_id];
+    const uint32_t mesh_vertex_offset = sv.meshes[d.mesh_index].vertex_offset;
+    float model[16];
+    load_m4(sv.transforms + (size_t)d.model_index * 16, model);
+    const rdr_meshlet* ml = &sv.meshlets[meshlet_index];
+    const uint8_t* tp = sv.meshlet_triangles + ml->triangle_offset + tri * 3;
+    const uint32_t* mv = sv.meshlet_vertices + ml->vertex_offset;
+    const uint32_t i1 = mesh_vertex_offset + mv[tp[0]], i2 = mesh_vertex_offset + mv[tp[1]], i3 = mesh_vertex_offset + mv[tp[2]];
+    const vec4 w1 = mul_m4(model, mk4(sv.pos_x[i1], sv.pos_y[i1], sv.pos_z[i1], 1.0f));
+    const vec4 w2 = mul_m4(model, mk4(sv.pos_x[i2], sv.pos_y[i2], sv.pos_z[i2], 1.0f));
+    const vec4 w3 = mul_m4(model, mk4(sv.pos_x[i3], sv.pos_y[i3], sv.pos_z[i3], 1.0f));
+    const vec4 c1 = mul_m4(u.view_proj, w1), c2 = mul_m4(u.view_proj, w2), c3 = mul_m4(u.view_proj, w3);
+    const BaryDeriv bary = calc_full_bary(c1, c2, c3, uvx * 2.0f - 1.0f, uvy * 2.0f - 1.0f, u.screen_width, u.screen_height);
+    return interp3(bary, mk3(w1.x, w1.y, w1.z), mk3(w2.x, w2.y, w2.z), mk3(w3.x, w3.y, w3.z));
+}
+
 RDR_DEV vec3 shade_pixel(const SceneView& sv, const rdr_ubo& u, uint32_t draw_id, uint32_t meshlet_index, uint32_t tri,
-                         float uvx, float uvy) {
+                         float uvx, float uvy, bool shadow_hit) {
     const rdr_mesh_draw d = sv.draws[draw_id];
     const uint32_t mesh_vertex_offset = sv.meshes[d.mesh_index].vertex_offset;
     float model[16];
@@ -353,7 +398,6 @@ RDR_DEV vec3 shade_pixel(const SceneView& sv, const rdr_ubo& u, uint32_t draw_id
     const vec3 nrm = normalize3((ntangent * nmap.x + bitangent * nmap.y) + nnormal * nmap.z);
 
     const vec3 L = normalize3(mk3(u.sun_direction[0], u.sun_direction[1], u.sun_direction[2]));
-    const bool shadow_hit = shadow_any_hit(sv, w_pos, L, 1e-2f, 1000.0f);
 
     const float metallic = clampf(mat.metallic_roughness_normal_occlusion[0] * mr.z, 0.0f, 1.0f);
     float prough = mr.y * mat.metallic_roughness_normal_occlusion[1];
@@ -426,11 +470,56 @@ RDR_DEV vec3 shade_pixel(const SceneView& sv, const rdr_ubo& u, uint32_t draw_id
     return color * (shadow_hit ? 0.35f : 1.0f);
 }
 
-__global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv) {
-    // 16x16 pixels per workgroup, each wave an 8x8 block
+// Decode a visibility key into (draw, meshlet, triangle).
+RDR_DEV void decode_key(const SceneView& sv, unsigned long long key, uint32_t& draw_id, uint32_t& meshlet, uint32_t& tri) {
+    const uint32_t id = (uint32_t)key, instance = id >> 7;
+    tri = id & 127u;
+    draw_id = sv.instance_draw[instance];
+    const rdr_mesh_draw d = sv.draws[draw_id];
+    const rdr_mesh_lod L = sv.meshes[d.mesh_index].lods[sv.draw_lod[draw_id]];
+    meshlet = L.meshlet_offset + (instance - d.meshlet_visibility_offset);
+}
+
+// 16x16 pixels per workgroup, each wave an 8x8 block.
+RDR_DEV void pixel_of_thread(const FrameView& fv, uint32_t& ix, uint32_t& iy) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t ix = blockIdx.x * 16 + (wave & 1u) * 8 + (lane & 7u);
-    const uint32_t iy = fv.row_lo + blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    ix = blockIdx.x * 16 + (wave & 1u) * 8 + (lane & 7u);
+    iy = fv.row_lo + blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+}
+
+// Pass 1: the sun shadow ray of every covered pixel (shading.frag.glsl:421-425), kept
+// apart from the material evaluation so that the pointer-chasing traversal runs at
+// high occupancy with its stack in LDS.
+__global__ __launch_bounds__(256) void k_shadow(SceneView sv, FrameView fv) {
+    __shared__ uint32_t stack_mem[kLdsStack * 256];
+    uint32_t ix, iy;
+    pixel_of_thread(fv, ix, iy);
+    if (ix >= fv.width || iy >= fv.row_hi) return;
+    const size_t pi = (size_t)iy * fv.width + ix;
+    const unsigned long long key = fv.vis[pi];
+    uint8_t hit = 0;
+    if (key != RDR_VIS_CLEAR) {
+        uint32_t draw_id, meshlet, tri;
+        decode_key(sv, key, draw_id, meshlet, tri);
+        const float uvx = ((float)ix + 0.5f) / (float)fv.width;
+        const float uvy = 1.0f - ((float)iy + 0.5f) / (float)fv.height;
+        const vec3 w_pos = pixel_world_position(sv, fv.ubo, draw_id, meshlet, tri, uvx, uvy);
+        const rdr_ubo& u = fv.ubo;
+        const vec3 L = normalize3(mk3(u.sun_direction[0], u.sun_direction[1], u.sun_direction[2]));
+        TraversalStack st;
+        st.lds = stack_mem + threadIdx.x;
+        st.stride = 256;
+        st.sp = 0;
+        hit = shadow_any_hit(sv, w_pos, L, 1e-2f, 1000.0f, st) ? 1 : 0;
+    }
+    fv.shadow[pi] = hit;
+}
+
+// Pass 2: material evaluation, lighting, sRGB store.
+__global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t ix, iy;
+    pixel_of_thread(fv, ix, iy);
     bool covered = false;
     if (ix < fv.width && iy < fv.row_hi) {
         const size_t pi = (size_t)iy * fv.width + ix;
@@ -438,30 +527,35 @@ __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv) {
         uint32_t out = 0u; // the shading pass clears its target to (0,0,0,0)
         if (key != RDR_VIS_CLEAR) {
             covered = true;
-            const uint32_t id = (uint32_t)key, instance = id >> 7, tri = id & 127u;
-            const uint32_t draw_id = sv.instance_draw[instance];
-            const rdr_mesh_draw d = sv.draws[draw_id];
-            const rdr_mesh_lod L = sv.meshes[d.mesh_index].lods[sv.draw_lod[draw_id]];
-            const uint32_t meshlet = L.meshlet_offset + (instance - d.meshlet_visibility_offset);
+            uint32_t draw_id, meshlet, tri;
+            decode_key(sv, key, draw_id, meshlet, tri);
             const float uvx = ((float)ix + 0.5f) / (float)fv.width;
             const float uvy = 1.0f - ((float)iy + 0.5f) / (float)fv.height;
-            const vec3 c = shade_pixel(sv, fv.ubo, draw_id, meshlet, tri, uvx, uvy);
+            const vec3 c = shade_pixel(sv, fv.ubo, draw_id, meshlet, tri, uvx, uvy, fv.shadow[pi] != 0);
             out = srgb_encode(c.x) | (srgb_encode(c.y) << 8) | (srgb_encode(c.z) << 16) | (255u << 24);
         }
         reinterpret_cast<uint32_t*>(fv.color)[pi] = out;
     }
     if (fv.collect_stats) {
+        __shared__ uint32_t wg_cov[4];
         const unsigned long long m = __ballot(covered);
-        if (lane == 0 && m) atomicAdd(&fv.counters->pixels_covered, (unsigned long long)__popcll(m));
+        if (lane == 0) wg_cov[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0)
+            fv.stat_slots[fv.grid.slot_shade + blockIdx.y * gridDim.x + blockIdx.x] = wg_cov[0] + wg_cov[1] + wg_cov[2] + wg_cov[3];
     }
 }
 
 } // namespace
 
-int rdr_launch_shade(const SceneView& sv, const FrameView& fv, hipStream_t stream) {
+int rdr_launch_shade(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev) {
     if (fv.row_hi <= fv.row_lo) return 0;
-    const dim3 grid((fv.width + 15) / 16, (fv.row_hi - fv.row_lo + 15) / 16);
+    const dim3 grid(fv.grid.shade_blocks_x, fv.grid.shade_blocks_y);
+    if (ev) RDR_HIP(hipEventRecord(ev[6], stream));
+    hipLaunchKernelGGL(k_shadow, grid, dim3(256), 0, stream, sv, fv);
+    if (ev) RDR_HIP(hipEventRecord(ev[7], stream));
     hipLaunchKernelGGL(k_shade, grid, dim3(256), 0, stream, sv, fv);
+    if (ev) RDR_HIP(hipEventRecord(ev[8], stream));
     RDR_HIP(hipGetLastError());
     return 0;
 }

@@ -198,7 +198,7 @@ def test_full_size_properties():
     g.render()
     full = g.read_visbuffer_u64()
     st = g.stats()
-    assert st["triangles_submitted"] == sc.triangle_count() == 1250 * 20480
+    assert st["triangles_submitted"] == st["draws_visible"] * 20480 <= sc.triangle_count() == 1250 * 20480
     cov = covered(full)
     assert st["pixels_covered"] == int(cov.sum()) > 0
     xy = g.read_visbuffer()
