@@ -9,6 +9,7 @@
 //   rdr_build_ubo         update_uniform_object      :1148-1197
 // There is no CPU fallback: every entry point needs a HIP device.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -92,7 +93,7 @@ struct rdr_renderer {
     DeviceBuffer<uint8_t> draw_lod;
     DeviceBuffer<GpuImage> images;
     DeviceBuffer<uint8_t> texels;
-    DeviceBuffer<BvhNode> tlas, blas;
+    DeviceBuffer<BvhPair> tlas, blas;
     DeviceBuffer<uint32_t> tlas_items;
     DeviceBuffer<float> blas_tris;
     DeviceBuffer<GpuInstance> instances;
@@ -108,6 +109,7 @@ struct rdr_renderer {
     uint32_t part_lo = 0, part_hi = 0xFFFFFFFFu;
     uint32_t row_lo = 0, row_hi = 0xFFFFFFFFu;
     uint32_t meshlet_visibility_count = 0;
+    uint32_t lds_stack_limit = 24;
     rdr_stats stats{};
 };
 
@@ -281,7 +283,7 @@ int pack_cubemap(TexelPacker& tp, const rdr_cubemap_desc* cm, GpuCubemap* out) {
 }
 
 int upload_tlas(rdr_renderer* r) {
-    if (r->tlas.upload(r->bvh.tlas_nodes.data(), r->bvh.tlas_nodes.size())) return 1;
+    if (r->tlas.upload(r->bvh.tlas_pairs.data(), r->bvh.tlas_pairs.size())) return 1;
     if (r->tlas_items.upload(r->bvh.tlas_items.data(), r->bvh.tlas_items.size())) return 1;
     if (r->instances.upload(r->bvh.instances.data(), r->bvh.instances.size())) return 1;
     r->sv.tlas = r->tlas.ptr;
@@ -308,6 +310,7 @@ FrameView make_frame_view(rdr_renderer* r) {
     fv.deferred_capacity = (uint32_t)r->deferred.count;
     fv.collect_stats = r->cfg.collect_stats;
     fv.shadow = r->shadow.ptr;
+    fv.lds_stack_limit = r->lds_stack_limit;
     fv.stat_slots = r->stat_slots.ptr;
     GridPlan& g = fv.grid;
     g.draw_blocks = std::max(1u, (r->sv.draw_count + 255u) / 256u);
@@ -356,6 +359,8 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
     std::unique_ptr<rdr_renderer> r(new rdr_renderer());
     if (cfg) r->cfg = *cfg;
     r->width = width; r->height = height; r->device = hip_devices[0];
+    if (const char* e = std::getenv("RDR_DEBUG_STACK_LIMIT")) // test hook: force the deep-stack shadow path
+        r->lds_stack_limit = (uint32_t)std::min(24, std::max(1, std::atoi(e)));
     RDR_HIP(hipSetDevice(r->device));
     RDR_HIP(hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking));
     r->stream = r->own_stream;
@@ -481,7 +486,7 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
     // shadow-ray structure
     rdr_build_blas(s, r->bvh);
     rdr_build_tlas(s, s.global_transforms, r->bvh);
-    if (r->blas.upload(r->bvh.blas_nodes.data(), r->bvh.blas_nodes.size())) return 1;
+    if (r->blas.upload(r->bvh.blas_pairs.data(), r->bvh.blas_pairs.size())) return 1;
     if (r->blas_tris.upload(r->bvh.blas_tris.data(), r->bvh.blas_tris.size())) return 1;
     r->h_draws.assign(s.mesh_draws, s.mesh_draws + s.draw_count);
     r->h_meshes.assign(s.meshes, s.meshes + s.mesh_count);

@@ -68,9 +68,9 @@ void build_rec(std::vector<BvhNode>& nodes, std::vector<Item>& items, uint32_t n
         nodes[node].left = (int32_t)first;
         nodes[node].count = (int32_t)count;
     };
-    if (count <= (uint32_t)kLeafSize || depth > 40) {
-        // depth guard: never deeper than the traversal stack allows
-        if (count <= 255) { make_leaf(); return; }
+    if (count <= (uint32_t)kLeafSize || (depth > 48 && count <= kBvhMaxLeaf)) {
+        make_leaf();
+        return;
     }
     int axis = 0;
     float ext = cbounds.hi[0] - cbounds.lo[0];
@@ -149,6 +149,33 @@ void build(std::vector<BvhNode>& nodes, std::vector<Item>& items) {
     build_rec(nodes, items, 0, 0, (uint32_t)items.size(), 0);
 }
 
+uint32_t leaf_code(const BvhNode& n) { return kBvhLeaf | ((uint32_t)n.count << 24) | (uint32_t)n.left; }
+
+// Flatten the binary tree into child-pair nodes (appended to `out`, indices relative to `base`).
+uint32_t emit_pairs(const std::vector<BvhNode>& nodes, uint32_t node, std::vector<BvhPair>& out, size_t base) {
+    const uint32_t self = (uint32_t)(out.size() - base);
+    out.emplace_back();
+    const BvhNode& l = nodes[nodes[node].left];
+    const BvhNode& r = nodes[nodes[node].left + 1];
+    uint32_t c0 = l.count ? leaf_code(l) : emit_pairs(nodes, (uint32_t)nodes[node].left, out, base);
+    uint32_t c1 = r.count ? leaf_code(r) : emit_pairs(nodes, (uint32_t)nodes[node].left + 1, out, base);
+    BvhPair& p = out[base + self];
+    for (int k = 0; k < 3; ++k) { p.lo0[k] = l.lo[k]; p.hi0[k] = l.hi[k]; p.lo1[k] = r.lo[k]; p.hi1[k] = r.hi[k]; }
+    p.child0 = c0; p.child1 = c1; p._pad0 = p._pad1 = 0;
+    return self;
+}
+
+void flatten(const std::vector<BvhNode>& nodes, std::vector<BvhPair>& out) {
+    const size_t base = out.size();
+    const BvhNode& root = nodes[0];
+    if (root.count == 0 && root.left != 0) { emit_pairs(nodes, 0, out, base); return; }
+    BvhPair p{};
+    p.child0 = root.count ? leaf_code(root) : kBvhNone;
+    p.child1 = kBvhNone;
+    for (int k = 0; k < 3; ++k) { p.lo0[k] = root.lo[k]; p.hi0[k] = root.hi[k]; }
+    out.push_back(p);
+}
+
 uint32_t mesh_index_count(const rdr_scene_desc& s, uint32_t mi) {
     const uint32_t end = mi + 1 < s.mesh_count ? s.meshes[mi + 1].index_offset : s.index_count;
     return end - s.meshes[mi].index_offset;
@@ -179,6 +206,8 @@ void affine_inverse(const float* m, float* out12) {
 
 void rdr_build_blas(const rdr_scene_desc& s, HostBvh& out) {
     out.blas_nodes.clear();
+    out.blas_pairs.clear();
+    out.mesh_bounds.assign(s.mesh_count, BvhNode{});
     out.blas_tris.clear();
     out.mesh_root.assign(s.mesh_count, 0);
     out.mesh_tri_base.assign(s.mesh_count, 0);
@@ -205,9 +234,10 @@ void rdr_build_blas(const rdr_scene_desc& s, HostBvh& out) {
             it.index = t;
         }
         build(nodes, items);
-        out.mesh_root[mi] = (uint32_t)out.blas_nodes.size();
+        out.mesh_root[mi] = (uint32_t)out.blas_pairs.size();
         out.mesh_tri_base[mi] = (uint32_t)(out.blas_tris.size() / 9);
-        out.blas_nodes.insert(out.blas_nodes.end(), nodes.begin(), nodes.end());
+        out.mesh_bounds[mi] = nodes[0];
+        flatten(nodes, out.blas_pairs);
         for (uint32_t t = 0; t < ntri; ++t) {
             for (int k = 0; k < 3; ++k) {
                 const uint32_t vi = s.indices[mesh.index_offset + 3 * items[t].index + k] + mesh.vertex_offset;
@@ -230,7 +260,7 @@ void rdr_build_tlas(const rdr_scene_desc& s, const float* transforms, HostBvh& i
         inst.blas_root = io.mesh_root[d.mesh_index];
         inst.tri_base = io.mesh_tri_base[d.mesh_index];
         inst._pad[0] = inst._pad[1] = 0;
-        const BvhNode& root = io.blas_nodes[inst.blas_root];
+        const BvhNode& root = io.mesh_bounds[d.mesh_index];
         Item& it = items[di];
         it.box.reset();
         it.index = di;
@@ -255,6 +285,8 @@ void rdr_build_tlas(const rdr_scene_desc& s, const float* transforms, HostBvh& i
         for (int k = 0; k < 3; ++k) it.c[k] = 0.5f * (it.box.lo[k] + it.box.hi[k]);
     }
     build(io.tlas_nodes, items);
+    io.tlas_pairs.clear();
+    flatten(io.tlas_nodes, io.tlas_pairs);
     io.tlas_items.resize(items.size());
     for (size_t i = 0; i < items.size(); ++i) io.tlas_items[i] = items[i].index;
 }

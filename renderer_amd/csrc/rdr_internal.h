@@ -65,7 +65,8 @@ struct FrameCounters {
     uint32_t vis_count;
     uint32_t deferred_count;
     uint32_t deferred_overflow;
-    uint32_t _pad0[12];
+    uint32_t shadow_overflow; // pixels k_shadow left to k_shadow_deep
+    uint32_t _pad0[11];
     unsigned long long _pad1[16];
 };
 static_assert(sizeof(FrameCounters) == 192, "FrameCounters layout");
@@ -86,6 +87,7 @@ struct GpuCubemap {
     uint64_t _pad2;
 };
 
+// Builder-side binary node.
 struct BvhNode {
     float lo[3];
     int32_t left; // inner: index of left child (right = left + 1); leaf: first item
@@ -94,9 +96,27 @@ struct BvhNode {
 };
 static_assert(sizeof(BvhNode) == 32, "BvhNode layout");
 
+// Traversal-side node: the boxes of the two children of one inner node plus what
+// each child is, in one 64-byte line.  A child code is kBvhNone, a leaf
+// (bit 31 | count << 24 | first item) or the index of the child's own pair.
+struct BvhPair {
+    float lo0[3];
+    uint32_t child0;
+    float hi0[3];
+    uint32_t child1;
+    float lo1[3];
+    uint32_t _pad0;
+    float hi1[3];
+    uint32_t _pad1;
+};
+static_assert(sizeof(BvhPair) == 64, "BvhPair layout");
+constexpr uint32_t kBvhNone = 0xFFFFFFFFu;
+constexpr uint32_t kBvhLeaf = 0x80000000u;
+constexpr uint32_t kBvhMaxLeaf = 127u;
+
 struct GpuInstance {
     float inv[12];      // rows of the inverse affine model matrix
-    uint32_t blas_root; // node index of the mesh's BLAS root
+    uint32_t blas_root; // index of the mesh's first BLAS pair
     uint32_t tri_base;  // first triangle of the mesh in the BLAS triangle array
     uint32_t _pad[2];
 };
@@ -121,8 +141,8 @@ struct SceneView {
     const float* srgb_lut;
     uint32_t draw_count, material_count, image_count, meshlet_count;
     // shadow-ray structure
-    const BvhNode* tlas;
-    const BvhNode* blas;
+    const BvhPair* tlas;
+    const BvhPair* blas;
     const uint32_t* tlas_items;
     const float* blas_tris; // 9 floats per triangle, leaf order
     const GpuInstance* instances;
@@ -152,6 +172,7 @@ struct FrameView {
     uint32_t command_capacity, visible_capacity, deferred_capacity;
     uint32_t collect_stats;
     uint8_t* shadow; // one byte per pixel: 1 = the sun ray is blocked
+    uint32_t lds_stack_limit; // entries of the LDS traversal stack in use (<= 24; lowered only by tests)
     // Per-workgroup statistics: every workgroup stores its partial counts in its own
     // slot with plain stores (no contended atomics); the host sums the slots on request.
     uint32_t* stat_slots;
@@ -160,6 +181,8 @@ struct FrameView {
 
 // ---- host BVH builder (rdr_bvh.cpp) -----------------------------------------
 struct HostBvh {
+    std::vector<BvhPair> blas_pairs, tlas_pairs;
+    std::vector<BvhNode> mesh_bounds; // per mesh: lo/hi of the whole BLAS
     std::vector<BvhNode> blas_nodes;
     std::vector<float> blas_tris;
     std::vector<uint32_t> mesh_root;     // per mesh

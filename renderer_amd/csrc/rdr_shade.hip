@@ -17,9 +17,9 @@ constexpr float kPi = 3.1415926535897932384626433832795f;
 constexpr float kMinRoughness = 0.04f;
 
 // ---- shadow ray -------------------------------------------------------------------
-RDR_DEV bool ray_box(const BvhNode& n, vec3 o, vec3 inv_d, float tmin, float tmax) {
+RDR_DEV bool ray_box(float lx, float ly, float lz, float hx, float hy, float hz, vec3 o, vec3 inv_d, float tmin, float tmax) {
     float t0 = tmin, t1 = tmax;
-    const float lo[3] = {n.lo[0], n.lo[1], n.lo[2]}, hi[3] = {n.hi[0], n.hi[1], n.hi[2]};
+    const float lo[3] = {lx, ly, lz}, hi[3] = {hx, hy, hz};
     const float oo[3] = {o.x, o.y, o.z}, id[3] = {inv_d.x, inv_d.y, inv_d.z};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -32,6 +32,16 @@ RDR_DEV bool ray_box(const BvhNode& n, vec3 o, vec3 inv_d, float tmin, float tma
         if (t0 > t1) return false;
     }
     return true;
+}
+
+// Test the two children of a pair and push the ones the ray may hit.
+template <typename Stack>
+RDR_DEV void visit_pair(const BvhPair* pp, vec3 o, vec3 inv_d, float tmin, float tmax, Stack& st) {
+    const float4* q = reinterpret_cast<const float4*>(pp);
+    const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+    const uint32_t c0 = __float_as_uint(a.w), c1 = __float_as_uint(b.w);
+    if (c0 != kBvhNone && ray_box(a.x, a.y, a.z, b.x, b.y, b.z, o, inv_d, tmin, tmax)) st.push(c0);
+    if (c1 != kBvhNone && ray_box(c.x, c.y, c.z, d.x, d.y, d.z, o, inv_d, tmin, tmax)) st.push(c1);
 }
 
 // Moeller-Trumbore, two-sided, open interval (tmin, tmax).
@@ -51,48 +61,52 @@ RDR_DEV bool ray_triangle(vec3 o, vec3 d, vec3 p0, vec3 p1, vec3 p2, float tmin,
     return t > tmin && t < tmax;
 }
 
-// Traversal stack: the first kLdsStack entries of each lane live in LDS (one
-// column per lane, so a wave's accesses are conflict-free), deeper entries spill
-// to a per-lane array.  The spill is never reached by reasonably balanced trees.
+// Traversal stacks.  The fast one keeps kLdsStack entries per lane in LDS (one
+// column per lane: conflict-free) and only records that it overflowed; a ray whose
+// traversal overflowed without finding a hit is traced again with the deep,
+// scratch-backed stack.  Reasonably balanced trees never reach the second path.
 constexpr int kLdsStack = 24;
-constexpr int kSpillStack = 40;
+constexpr int kDeepStack = 160;
 
-struct TraversalStack {
-    uint32_t* lds; // &shared[lane], stride = block size
-    uint32_t stride;
-    uint32_t spill[kSpillStack];
-    int sp;
+struct LdsStack {
+    uint32_t* base; // &shared[thread], stride 256 entries
+    int sp, limit;
+    bool overflow;
     RDR_DEV void push(uint32_t v) {
-        if (sp < kLdsStack) lds[sp * stride] = v;
-        else if (sp < kLdsStack + kSpillStack) spill[sp - kLdsStack] = v;
-        ++sp;
+        if (sp < limit) base[sp * 256] = v;
+        else overflow = true;
+        sp += sp < limit ? 1 : 0;
     }
-    RDR_DEV uint32_t pop() {
-        --sp;
-        return sp < kLdsStack ? lds[sp * stride] : spill[min(sp - kLdsStack, kSpillStack - 1)];
-    }
+    RDR_DEV uint32_t pop() { return base[--sp * 256]; }
 };
 
-// Any-hit over one mesh's BLAS in object space.  Entries on the stack are node
-// indices relative to the mesh's root; `floor` is the stack height to stop at.
-RDR_DEV bool blas_any_hit(const SceneView& sv, const GpuInstance& inst, vec3 o, vec3 d, float tmin, float tmax,
-                          TraversalStack& st) {
+struct DeepStack {
+    uint32_t data[kDeepStack];
+    int sp;
+    bool overflow;
+    RDR_DEV void push(uint32_t v) {
+        if (sp < kDeepStack) data[sp++] = v;
+        else overflow = true;
+    }
+    RDR_DEV uint32_t pop() { return data[--sp]; }
+};
+
+// Any-hit over one mesh's BLAS in object space.  Stack entries are child codes.
+template <typename Stack>
+RDR_DEV bool blas_any_hit(const SceneView& sv, const GpuInstance& inst, vec3 o, vec3 d, float tmin, float tmax, Stack& st) {
     const vec3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const BvhNode* nodes = sv.blas + inst.blas_root;
+    const BvhPair* pairs = sv.blas + inst.blas_root;
     const int floor = st.sp;
-    if (!ray_box(nodes[0], o, inv_d, tmin, tmax)) return false;
     st.push(0u);
     while (st.sp > floor) {
-        const BvhNode n = nodes[st.pop()];
-        if (n.count == 0) {
-            if (n.left == 0) continue; // empty mesh
-            const BvhNode l = nodes[n.left], r = nodes[n.left + 1];
-            if (ray_box(l, o, inv_d, tmin, tmax)) st.push((uint32_t)n.left);
-            if (ray_box(r, o, inv_d, tmin, tmax)) st.push((uint32_t)n.left + 1u);
+        const uint32_t code = st.pop();
+        if (!(code & kBvhLeaf)) {
+            visit_pair(pairs + code, o, inv_d, tmin, tmax, st);
             continue;
         }
-        const float* tp = sv.blas_tris + ((size_t)inst.tri_base + (uint32_t)n.left) * 9;
-        for (int i = 0; i < n.count; ++i, tp += 9) {
+        const uint32_t count = (code >> 24) & 127u, first = code & 0xFFFFFFu;
+        const float* tp = sv.blas_tris + ((size_t)inst.tri_base + first) * 9;
+        for (uint32_t i = 0; i < count; ++i, tp += 9) {
             if (ray_triangle(o, d, mk3(tp[0], tp[1], tp[2]), mk3(tp[3], tp[4], tp[5]), mk3(tp[6], tp[7], tp[8]), tmin, tmax)) {
                 st.sp = floor;
                 return true;
@@ -102,30 +116,38 @@ RDR_DEV bool blas_any_hit(const SceneView& sv, const GpuInstance& inst, vec3 o, 
     return false;
 }
 
-RDR_DEV bool shadow_any_hit(const SceneView& sv, vec3 o, vec3 d, float tmin, float tmax, TraversalStack& st) {
-    if (sv.draw_count == 0) return false;
-    const vec3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+template <typename Stack>
+RDR_DEV bool instance_any_hit(const SceneView& sv, uint32_t instance, vec3 o, vec3 d, float tmin, float tmax, Stack& st) {
+    const GpuInstance& inst = sv.instances[instance];
+    const float* iv = inst.inv;
+    const vec3 oo = mk3(((iv[0] * o.x + iv[1] * o.y) + iv[2] * o.z) + iv[3], ((iv[4] * o.x + iv[5] * o.y) + iv[6] * o.z) + iv[7],
+                        ((iv[8] * o.x + iv[9] * o.y) + iv[10] * o.z) + iv[11]);
+    const vec3 od = mk3((iv[0] * d.x + iv[1] * d.y) + iv[2] * d.z, (iv[4] * d.x + iv[5] * d.y) + iv[6] * d.z,
+                        (iv[8] * d.x + iv[9] * d.y) + iv[10] * d.z);
+    return blas_any_hit(sv, inst, oo, od, tmin, tmax, st);
+}
+
+// Is anything between the surface point and the sun?  The result is a plain "any
+// triangle hit", so the order instances are visited in is free: the pixel's own
+// instance, by far the likeliest occluder, goes first and is skipped afterwards.
+template <typename Stack>
+RDR_DEV bool shadow_any_hit(const SceneView& sv, uint32_t own_instance, vec3 o, vec3 d, float tmin, float tmax, Stack& st) {
     st.sp = 0;
-    if (!ray_box(sv.tlas[0], o, inv_d, tmin, tmax)) return false;
+    st.overflow = false;
+    if (instance_any_hit(sv, own_instance, o, d, tmin, tmax, st)) return true;
+    const vec3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     st.push(0u);
     while (st.sp > 0) {
-        const BvhNode n = sv.tlas[st.pop()];
-        if (n.count == 0) {
-            if (n.left == 0) continue;
-            const BvhNode l = sv.tlas[n.left], r = sv.tlas[n.left + 1];
-            if (ray_box(l, o, inv_d, tmin, tmax)) st.push((uint32_t)n.left);
-            if (ray_box(r, o, inv_d, tmin, tmax)) st.push((uint32_t)n.left + 1u);
+        const uint32_t code = st.pop();
+        if (!(code & kBvhLeaf)) {
+            visit_pair(sv.tlas + code, o, inv_d, tmin, tmax, st);
             continue;
         }
-        for (int i = 0; i < n.count; ++i) {
-            const GpuInstance& inst = sv.instances[sv.tlas_items[n.left + i]];
-            const float* iv = inst.inv;
-            const vec3 oo = mk3(((iv[0] * o.x + iv[1] * o.y) + iv[2] * o.z) + iv[3],
-                                ((iv[4] * o.x + iv[5] * o.y) + iv[6] * o.z) + iv[7],
-                                ((iv[8] * o.x + iv[9] * o.y) + iv[10] * o.z) + iv[11]);
-            const vec3 od = mk3((iv[0] * d.x + iv[1] * d.y) + iv[2] * d.z, (iv[4] * d.x + iv[5] * d.y) + iv[6] * d.z,
-                                (iv[8] * d.x + iv[9] * d.y) + iv[10] * d.z);
-            if (blas_any_hit(sv, inst, oo, od, tmin, tmax, st)) return true;
+        const uint32_t count = (code >> 24) & 127u, first = code & 0xFFFFFFu;
+        for (uint32_t i = 0; i < count; ++i) {
+            const uint32_t instance = sv.tlas_items[first + i];
+            if (instance == own_instance) continue;
+            if (instance_any_hit(sv, instance, o, d, tmin, tmax, st)) return true;
         }
     }
     return false;
@@ -506,13 +528,37 @@ __global__ __launch_bounds__(256) void k_shadow(SceneView sv, FrameView fv) {
         const vec3 w_pos = pixel_world_position(sv, fv.ubo, draw_id, meshlet, tri, uvx, uvy);
         const rdr_ubo& u = fv.ubo;
         const vec3 L = normalize3(mk3(u.sun_direction[0], u.sun_direction[1], u.sun_direction[2]));
-        TraversalStack st;
-        st.lds = stack_mem + threadIdx.x;
-        st.stride = 256;
-        st.sp = 0;
-        hit = shadow_any_hit(sv, w_pos, L, 1e-2f, 1000.0f, st) ? 1 : 0;
+        LdsStack st;
+        st.base = stack_mem + threadIdx.x;
+        st.limit = (int)fv.lds_stack_limit;
+        const bool h = shadow_any_hit(sv, draw_id, w_pos, L, 1e-2f, 1000.0f, st);
+        hit = h ? 1 : 0;
+        if (!h && st.overflow) { // a miss that dropped stack entries proves nothing: leave it to k_shadow_deep
+            hit = 2;
+            atomicAdd(&fv.counters->shadow_overflow, 1u);
+        }
     }
     fv.shadow[pi] = hit;
+}
+
+// Pass 1b: pixels whose traversal overflowed the LDS stack, traced again with the deep
+// scratch-backed stack.  Exits at once when there are none (the normal case).
+__global__ __launch_bounds__(256) void k_shadow_deep(SceneView sv, FrameView fv) {
+    if (fv.counters->shadow_overflow == 0u) return;
+    const size_t first = (size_t)fv.row_lo * fv.width, last = (size_t)fv.row_hi * fv.width;
+    const rdr_ubo& u = fv.ubo;
+    for (size_t pi = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x; pi < last; pi += (size_t)gridDim.x * blockDim.x) {
+        if (fv.shadow[pi] != 2) continue;
+        const uint32_t ix = (uint32_t)(pi % fv.width), iy = (uint32_t)(pi / fv.width);
+        uint32_t draw_id, meshlet, tri;
+        decode_key(sv, fv.vis[pi], draw_id, meshlet, tri);
+        const float uvx = ((float)ix + 0.5f) / (float)fv.width;
+        const float uvy = 1.0f - ((float)iy + 0.5f) / (float)fv.height;
+        const vec3 w_pos = pixel_world_position(sv, u, draw_id, meshlet, tri, uvx, uvy);
+        const vec3 L = normalize3(mk3(u.sun_direction[0], u.sun_direction[1], u.sun_direction[2]));
+        DeepStack st;
+        fv.shadow[pi] = shadow_any_hit(sv, draw_id, w_pos, L, 1e-2f, 1000.0f, st) ? 1 : 0;
+    }
 }
 
 // Pass 2: material evaluation, lighting, sRGB store.
@@ -553,6 +599,7 @@ int rdr_launch_shade(const SceneView& sv, const FrameView& fv, hipStream_t strea
     const dim3 grid(fv.grid.shade_blocks_x, fv.grid.shade_blocks_y);
     if (ev) RDR_HIP(hipEventRecord(ev[6], stream));
     hipLaunchKernelGGL(k_shadow, grid, dim3(256), 0, stream, sv, fv);
+    hipLaunchKernelGGL(k_shadow_deep, dim3(512), dim3(256), 0, stream, sv, fv);
     if (ev) RDR_HIP(hipEventRecord(ev[7], stream));
     hipLaunchKernelGGL(k_shade, grid, dim3(256), 0, stream, sv, fv);
     if (ev) RDR_HIP(hipEventRecord(ev[8], stream));

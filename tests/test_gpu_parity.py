@@ -100,6 +100,15 @@ def test_alpha_masked_field(oracle):
     check_color(o, g)
 
 
+def test_shadow_deep_stack_path(oracle, monkeypatch):
+    """Rays whose traversal overflows the LDS stack are re-traced with the deep stack."""
+    monkeypatch.setenv("RDR_DEBUG_STACK_LIMIT", "3")
+    sc = synth.make_atrium()
+    o, ovis, g = both(oracle, sc, 256, 144)
+    check_vis(o, ovis, g)
+    check_color(o, g)
+
+
 def test_known_answer_triangle():
     W = H = 64
     sc = fb_triangle_scene([[(8, 8, 5.0), (8, 40, 5.0), (40, 8, 5.0)]], W, H)
