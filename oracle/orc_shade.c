@@ -21,8 +21,8 @@
  * Choices where the Vulkan implementation has latitude: texture(brdf_lut) and
  * texture(lambertian) use LOD 0 (their implicit LOD depends on quad
  * derivatives); pow(x, 5) and pow(x, 2) are exact products; the ray/triangle
- * test is Moeller-Trumbore in object space with the instance transform
- * inverted in double precision; a ray hits when tmin < t < tmax.
+ * test is a division-free Moeller-Trumbore in object space with the instance
+ * transform inverted in double precision; a ray hits when tmin < t < tmax.
  */
 #include <stdlib.h>
 #include <stdio.h>
@@ -128,21 +128,22 @@ static int ray_box(const float* lo, const float* hi, const float* o, const float
     return 1;
 }
 
-/* Moeller-Trumbore, two-sided, open interval (tmin, tmax). */
+/* Moeller-Trumbore without the division, two-sided, open interval (tmin, tmax):
+ * with a = |det| and the numerators multiplied by sign(det), the ray hits when
+ * U >= 0, V >= 0, U + V <= a and tmin * a < T < tmax * a. */
 static int ray_triangle(v3 o, v3 d, v3 p0, v3 p1, v3 p2, float tmin, float tmax) {
     v3 e1 = v3_sub(p1, p0), e2 = v3_sub(p2, p0);
     v3 pv = v3_cross(d, e2);
     float det = v3_dot(e1, pv);
     if (det == 0.0f) return 0;
-    float inv = 1.0f / det;
     v3 tv = v3_sub(o, p0);
-    float u = v3_dot(tv, pv) * inv;
-    if (!(u >= 0.0f && u <= 1.0f)) return 0;
+    float un = v3_dot(tv, pv);
     v3 qv = v3_cross(tv, e1);
-    float v = v3_dot(d, qv) * inv;
-    if (!(v >= 0.0f && u + v <= 1.0f)) return 0;
-    float t = v3_dot(e2, qv) * inv;
-    return t > tmin && t < tmax;
+    float vn = v3_dot(d, qv);
+    float tn = v3_dot(e2, qv);
+    float sgn = det < 0.0f ? -1.0f : 1.0f;
+    float a = fabsf(det), U = un * sgn, V = vn * sgn, T = tn * sgn;
+    return U >= 0.0f && V >= 0.0f && U + V <= a && T > tmin * a && T < tmax * a;
 }
 
 typedef struct {

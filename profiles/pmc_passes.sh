@@ -1,12 +1,13 @@
 #!/bin/bash
 # Counter passes (one rocprofv3 run each; never combined with tracing). Usage: pmc_passes.sh <outdir> [scene]
 set -u
-OUT=$1; SCENE=${2:-field}
+OUT=$1; SCENE=${2:-field}; ONLY=${3:-all}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $OUT
 run() { # name counters...
   name=$1; shift
+  if [ "$ONLY" != "all" ] && [[ ",$ONLY," != *",$name,"* ]]; then return 0; fi
   timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/profiles/run_frames.py 3 $SCENE > $OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -3 $OUT/$name.log; return 1; }
   echo "pass $name ok"
 }

@@ -93,7 +93,7 @@ struct rdr_renderer {
     DeviceBuffer<uint8_t> draw_lod;
     DeviceBuffer<GpuImage> images;
     DeviceBuffer<uint8_t> texels;
-    DeviceBuffer<BvhPair> tlas, blas;
+    DeviceBuffer<BvhWide> bvh_dev; // bottom levels followed by room for the top level
     DeviceBuffer<uint32_t> tlas_items;
     DeviceBuffer<float> blas_tris;
     DeviceBuffer<GpuInstance> instances;
@@ -283,10 +283,13 @@ int pack_cubemap(TexelPacker& tp, const rdr_cubemap_desc* cm, GpuCubemap* out) {
 }
 
 int upload_tlas(rdr_renderer* r) {
-    if (r->tlas.upload(r->bvh.tlas_pairs.data(), r->bvh.tlas_pairs.size())) return 1;
+    const size_t blas_count = r->bvh.blas_pairs.size();
+    RDR_CHECK(blas_count + r->bvh.tlas_pairs.size() <= r->bvh_dev.count, "internal: top-level BVH larger than reserved");
+    RDR_HIP(hipMemcpy(r->bvh_dev.ptr + blas_count, r->bvh.tlas_pairs.data(), r->bvh.tlas_pairs.size() * sizeof(BvhWide), hipMemcpyHostToDevice));
     if (r->tlas_items.upload(r->bvh.tlas_items.data(), r->bvh.tlas_items.size())) return 1;
     if (r->instances.upload(r->bvh.instances.data(), r->bvh.instances.size())) return 1;
-    r->sv.tlas = r->tlas.ptr;
+    r->sv.bvh = r->bvh_dev.ptr;
+    r->sv.tlas_base = (uint32_t)blas_count;
     r->sv.tlas_items = r->tlas_items.ptr;
     r->sv.instances = r->instances.ptr;
     return 0;
@@ -486,7 +489,9 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
     // shadow-ray structure
     rdr_build_blas(s, r->bvh);
     rdr_build_tlas(s, s.global_transforms, r->bvh);
-    if (r->blas.upload(r->bvh.blas_pairs.data(), r->bvh.blas_pairs.size())) return 1;
+    if (r->bvh_dev.alloc(r->bvh.blas_pairs.size() + (size_t)s.draw_count + 2)) return 1;
+    if (!r->bvh.blas_pairs.empty())
+        RDR_HIP(hipMemcpy(r->bvh_dev.ptr, r->bvh.blas_pairs.data(), r->bvh.blas_pairs.size() * sizeof(BvhWide), hipMemcpyHostToDevice));
     if (r->blas_tris.upload(r->bvh.blas_tris.data(), r->bvh.blas_tris.size())) return 1;
     r->h_draws.assign(s.mesh_draws, s.mesh_draws + s.draw_count);
     r->h_meshes.assign(s.meshes, s.meshes + s.mesh_count);
@@ -510,7 +515,6 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
     sv.material_count = s.material_count;
     sv.image_count = s.image_count;
     sv.meshlet_count = s.meshlet_count;
-    sv.blas = r->blas.ptr;
     sv.blas_tris = r->blas_tris.ptr;
     if (upload_tlas(r)) return 1;
     r->meshlet_visibility_count = s.meshlet_visibility_count;

@@ -47,7 +47,7 @@ struct Item {
 };
 
 constexpr int kBins = 12;
-constexpr int kLeafSize = 4;
+constexpr int kLeafSize = 2;
 
 // Recursive binned-SAH build over items[first, first+count). Node indices are
 // relative to `nodes` (the caller offsets them), children adjacent.
@@ -149,31 +149,105 @@ void build(std::vector<BvhNode>& nodes, std::vector<Item>& items) {
     build_rec(nodes, items, 0, 0, (uint32_t)items.size(), 0);
 }
 
+// float -> half with directed rounding (down: largest half <= x, up: smallest half >= x).
+float half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 31u, man = h & 1023u;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else { // subnormal
+            int e = -1;
+            uint32_t m = man;
+            do { m <<= 1; ++e; } while (!(m & 1024u));
+            bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((m & 1023u) << 13);
+        }
+    } else if (exp == 31) bits = sign | 0x7F800000u | (man << 13);
+    else bits = sign | ((exp + 112u) << 23) | (man << 13);
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+}
+uint16_t float_to_half_dir(float x, bool up) {
+    if (std::isnan(x)) return up ? 0x7C00u : 0xFC00u; // unbounded side
+    // candidates ordered as signed magnitudes: search the monotone sequence by bisection
+    // over the 16-bit ordered key (0x0000..0x7C00 positive, mirrored negative)
+    auto key_to_half = [](int k) -> uint16_t { return k >= 0 ? (uint16_t)k : (uint16_t)(0x8000u | (uint32_t)(-k)); };
+    int lo = -0x7C00, hi = 0x7C00; // -inf .. +inf
+    if (up) { // smallest k with value >= x
+        while (lo < hi) {
+            const int mid = lo + (hi - lo) / 2;
+            if (half_to_float(key_to_half(mid)) >= x) hi = mid; else lo = mid + 1;
+        }
+    } else { // largest k with value <= x
+        while (lo < hi) {
+            const int mid = lo + (hi - lo + 1) / 2;
+            if (half_to_float(key_to_half(mid)) <= x) lo = mid; else hi = mid - 1;
+        }
+    }
+    return key_to_half(lo);
+}
+
 uint32_t leaf_code(const BvhNode& n) { return kBvhLeaf | ((uint32_t)n.count << 24) | (uint32_t)n.left; }
 
-// Flatten the binary tree into child-pair nodes (appended to `out`, indices relative to `base`).
-uint32_t emit_pairs(const std::vector<BvhNode>& nodes, uint32_t node, std::vector<BvhPair>& out, size_t base) {
+float node_half_area(const BvhNode& n) {
+    const float dx = n.hi[0] - n.lo[0], dy = n.hi[1] - n.lo[1], dz = n.hi[2] - n.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// Collapse the binary tree into kBvhWidth-wide nodes (appended to `out`, indices relative to
+// `base`): starting from a node's two children, the inner child with the largest surface is
+// replaced by its own two children until the node is full.
+uint32_t emit_wide(const std::vector<BvhNode>& nodes, uint32_t node, std::vector<BvhWide>& out, size_t base) {
     const uint32_t self = (uint32_t)(out.size() - base);
     out.emplace_back();
-    const BvhNode& l = nodes[nodes[node].left];
-    const BvhNode& r = nodes[nodes[node].left + 1];
-    uint32_t c0 = l.count ? leaf_code(l) : emit_pairs(nodes, (uint32_t)nodes[node].left, out, base);
-    uint32_t c1 = r.count ? leaf_code(r) : emit_pairs(nodes, (uint32_t)nodes[node].left + 1, out, base);
-    BvhPair& p = out[base + self];
-    for (int k = 0; k < 3; ++k) { p.lo0[k] = l.lo[k]; p.hi0[k] = l.hi[k]; p.lo1[k] = r.lo[k]; p.hi1[k] = r.hi[k]; }
-    p.child0 = c0; p.child1 = c1; p._pad0 = p._pad1 = 0;
+    uint32_t slots[kBvhWidth];
+    int n = 2;
+    slots[0] = (uint32_t)nodes[node].left;
+    slots[1] = (uint32_t)nodes[node].left + 1;
+    while (n < kBvhWidth) {
+        int best = -1;
+        float best_area = -1.0f;
+        for (int i = 0; i < n; ++i) {
+            if (nodes[slots[i]].count != 0) continue;
+            const float a = node_half_area(nodes[slots[i]]);
+            if (a > best_area) { best_area = a; best = i; }
+        }
+        if (best < 0) break;
+        const uint32_t l = (uint32_t)nodes[slots[best]].left;
+        slots[best] = l;
+        slots[n++] = l + 1;
+    }
+    uint32_t codes[kBvhWidth];
+    for (int i = 0; i < kBvhWidth; ++i) {
+        if (i >= n) { codes[i] = kBvhNone; continue; }
+        const BvhNode& c = nodes[slots[i]];
+        codes[i] = c.count ? leaf_code(c) : emit_wide(nodes, slots[i], out, base);
+    }
+    BvhWide& w = out[base + self];
+    for (int i = 0; i < kBvhWidth; ++i) {
+        w.child[i] = codes[i];
+        for (int k = 0; k < 3; ++k) {
+            w.box[i][k] = i < n ? float_to_half_dir(nodes[slots[i]].lo[k], false) : (uint16_t)0;
+            w.box[i][3 + k] = i < n ? float_to_half_dir(nodes[slots[i]].hi[k], true) : (uint16_t)0;
+        }
+    }
     return self;
 }
 
-void flatten(const std::vector<BvhNode>& nodes, std::vector<BvhPair>& out) {
+void flatten(const std::vector<BvhNode>& nodes, std::vector<BvhWide>& out) {
     const size_t base = out.size();
     const BvhNode& root = nodes[0];
-    if (root.count == 0 && root.left != 0) { emit_pairs(nodes, 0, out, base); return; }
-    BvhPair p{};
-    p.child0 = root.count ? leaf_code(root) : kBvhNone;
-    p.child1 = kBvhNone;
-    for (int k = 0; k < 3; ++k) { p.lo0[k] = root.lo[k]; p.hi0[k] = root.hi[k]; }
-    out.push_back(p);
+    if (root.count == 0 && root.left != 0) { emit_wide(nodes, 0, out, base); return; }
+    BvhWide w{};
+    for (int i = 0; i < kBvhWidth; ++i) w.child[i] = kBvhNone;
+    if (root.count) {
+        w.child[0] = leaf_code(root);
+        for (int k = 0; k < 3; ++k) {
+            w.box[0][k] = float_to_half_dir(root.lo[k], false);
+            w.box[0][3 + k] = float_to_half_dir(root.hi[k], true);
+        }
+    }
+    out.push_back(w);
 }
 
 uint32_t mesh_index_count(const rdr_scene_desc& s, uint32_t mi) {
@@ -239,12 +313,12 @@ void rdr_build_blas(const rdr_scene_desc& s, HostBvh& out) {
         out.mesh_bounds[mi] = nodes[0];
         flatten(nodes, out.blas_pairs);
         for (uint32_t t = 0; t < ntri; ++t) {
-            for (int k = 0; k < 3; ++k) {
-                const uint32_t vi = s.indices[mesh.index_offset + 3 * items[t].index + k] + mesh.vertex_offset;
-                out.blas_tris.push_back(s.vertices[vi].p[0]);
-                out.blas_tris.push_back(s.vertices[vi].p[1]);
-                out.blas_tris.push_back(s.vertices[vi].p[2]);
-            }
+            // stored as p0, e1 = p1 - p0, e2 = p2 - p0 (single-precision differences)
+            const float* p[3];
+            for (int k = 0; k < 3; ++k) p[k] = s.vertices[s.indices[mesh.index_offset + 3 * items[t].index + k] + mesh.vertex_offset].p;
+            for (int c = 0; c < 3; ++c) out.blas_tris.push_back(p[0][c]);
+            for (int c = 0; c < 3; ++c) out.blas_tris.push_back(p[1][c] - p[0][c]);
+            for (int c = 0; c < 3; ++c) out.blas_tris.push_back(p[2][c] - p[0][c]);
         }
     }
 }

@@ -96,27 +96,23 @@ struct BvhNode {
 };
 static_assert(sizeof(BvhNode) == 32, "BvhNode layout");
 
-// Traversal-side node: the boxes of the two children of one inner node plus what
-// each child is, in one 64-byte line.  A child code is kBvhNone, a leaf
-// (bit 31 | count << 24 | first item) or the index of the child's own pair.
-struct BvhPair {
-    float lo0[3];
-    uint32_t child0;
-    float hi0[3];
-    uint32_t child1;
-    float lo1[3];
-    uint32_t _pad0;
-    float hi1[3];
-    uint32_t _pad1;
+// Traversal-side node: kBvhWidth children, each a code and a box of 6 halfs
+// (lo.xyz hi.xyz, rounded outward so the box only grows).  A child code is
+// kBvhNone, a leaf (bit 31 | count << 24 | first item) or the index of the child's
+// own node.  Wide nodes keep the dependent-load chain of a traversal short.
+constexpr int kBvhWidth = 4;
+struct BvhWide {
+    uint32_t child[kBvhWidth];
+    uint16_t box[kBvhWidth][6];
 };
-static_assert(sizeof(BvhPair) == 64, "BvhPair layout");
+static_assert(sizeof(BvhWide) == kBvhWidth * 16, "BvhWide layout");
 constexpr uint32_t kBvhNone = 0xFFFFFFFFu;
 constexpr uint32_t kBvhLeaf = 0x80000000u;
 constexpr uint32_t kBvhMaxLeaf = 127u;
 
 struct GpuInstance {
     float inv[12];      // rows of the inverse affine model matrix
-    uint32_t blas_root; // index of the mesh's first BLAS pair
+    uint32_t blas_root; // index of the mesh's first BLAS node
     uint32_t tri_base;  // first triangle of the mesh in the BLAS triangle array
     uint32_t _pad[2];
 };
@@ -141,8 +137,8 @@ struct SceneView {
     const float* srgb_lut;
     uint32_t draw_count, material_count, image_count, meshlet_count;
     // shadow-ray structure
-    const BvhPair* tlas;
-    const BvhPair* blas;
+    const BvhWide* bvh;  // every mesh's bottom-level nodes, then the top-level nodes
+    uint32_t tlas_base;  // index of the top level's node 0 in `bvh`
     const uint32_t* tlas_items;
     const float* blas_tris; // 9 floats per triangle, leaf order
     const GpuInstance* instances;
@@ -181,7 +177,7 @@ struct FrameView {
 
 // ---- host BVH builder (rdr_bvh.cpp) -----------------------------------------
 struct HostBvh {
-    std::vector<BvhPair> blas_pairs, tlas_pairs;
+    std::vector<BvhWide> blas_pairs, tlas_pairs;
     std::vector<BvhNode> mesh_bounds; // per mesh: lo/hi of the whole BLAS
     std::vector<BvhNode> blas_nodes;
     std::vector<float> blas_tris;

@@ -17,48 +17,40 @@ constexpr float kPi = 3.1415926535897932384626433832795f;
 constexpr float kMinRoughness = 0.04f;
 
 // ---- shadow ray -------------------------------------------------------------------
+// Conservative ray / box slab test.  Only "never miss a box the ray touches" matters
+// for the result, so this uses the fast reciprocal and one widening of the final
+// interval (4e-6 relative, far above the accumulated rounding of ~3e-7).  NaNs
+// from 0 * inf fall out of min/max and never reject.
 RDR_DEV bool ray_box(float lx, float ly, float lz, float hx, float hy, float hz, vec3 o, vec3 inv_d, float tmin, float tmax) {
-    float t0 = tmin, t1 = tmax;
-    const float lo[3] = {lx, ly, lz}, hi[3] = {hx, hy, hz};
-    const float oo[3] = {o.x, o.y, o.z}, id[3] = {inv_d.x, inv_d.y, inv_d.z};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        float tn = (lo[k] - oo[k]) * id[k], tf = (hi[k] - oo[k]) * id[k];
-        if (tn > tf) { const float t = tn; tn = tf; tf = t; }
-        tn = tn - 4e-6f * fabsf(tn);
-        tf = tf + 4e-6f * fabsf(tf);
-        if (tn > t0) t0 = tn; // NaN (0 * inf) never rejects
-        if (tf < t1) t1 = tf;
-        if (t0 > t1) return false;
-    }
-    return true;
+    const float ax = (lx - o.x) * inv_d.x, bx = (hx - o.x) * inv_d.x;
+    const float ay = (ly - o.y) * inv_d.y, by = (hy - o.y) * inv_d.y;
+    const float az = (lz - o.z) * inv_d.z, bz = (hz - o.z) * inv_d.z;
+    const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+    const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    return fmaf(-4e-6f, fabsf(t_in), t_in) <= fmaf(4e-6f, fabsf(t_out), t_out);
 }
 
-// Test the two children of a pair and push the ones the ray may hit.
-template <typename Stack>
-RDR_DEV void visit_pair(const BvhPair* pp, vec3 o, vec3 inv_d, float tmin, float tmax, Stack& st) {
-    const float4* q = reinterpret_cast<const float4*>(pp);
-    const float4 a = q[0], b = q[1], c = q[2], d = q[3];
-    const uint32_t c0 = __float_as_uint(a.w), c1 = __float_as_uint(b.w);
-    if (c0 != kBvhNone && ray_box(a.x, a.y, a.z, b.x, b.y, b.z, o, inv_d, tmin, tmax)) st.push(c0);
-    if (c1 != kBvhNone && ray_box(c.x, c.y, c.z, d.x, d.y, d.z, o, inv_d, tmin, tmax)) st.push(c1);
-}
+RDR_DEV float half_lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xFFFFu)); }
+RDR_DEV float half_hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
 
-// Moeller-Trumbore, two-sided, open interval (tmin, tmax).
-RDR_DEV bool ray_triangle(vec3 o, vec3 d, vec3 p0, vec3 p1, vec3 p2, float tmin, float tmax) {
-    const vec3 e1 = p1 - p0, e2 = p2 - p0;
+// Moeller-Trumbore without the division, two-sided, open interval (tmin, tmax): with
+// a = |det| and the numerators multiplied by sign(det), the ray hits when
+// U >= 0, V >= 0, U + V <= a and tmin * a < T < tmax * a.  e1 = p1 - p0 and
+// e2 = p2 - p0 are stored with the triangle.
+RDR_DEV bool ray_triangle(vec3 o, vec3 d, vec3 p0, vec3 e1, vec3 e2, float tmin, float tmax) {
     const vec3 pv = cross3(d, e2);
     const float det = dot3(e1, pv);
-    if (det == 0.0f) return false;
-    const float inv = 1.0f / det;
     const vec3 tv = o - p0;
-    const float u = dot3(tv, pv) * inv;
-    if (!(u >= 0.0f && u <= 1.0f)) return false;
+    const float un = dot3(tv, pv);
     const vec3 qv = cross3(tv, e1);
-    const float v = dot3(d, qv) * inv;
-    if (!(v >= 0.0f && u + v <= 1.0f)) return false;
-    const float t = dot3(e2, qv) * inv;
-    return t > tmin && t < tmax;
+    const float vn = dot3(d, qv);
+    const float tn = dot3(e2, qv);
+    const uint32_t sign = __float_as_uint(det) & 0x80000000u;
+    const float a = fabsf(det);
+    const float U = __uint_as_float(__float_as_uint(un) ^ sign);
+    const float V = __uint_as_float(__float_as_uint(vn) ^ sign);
+    const float T = __uint_as_float(__float_as_uint(tn) ^ sign);
+    return det != 0.0f && U >= 0.0f && V >= 0.0f && U + V <= a && T > tmin * a && T < tmax * a;
 }
 
 // Traversal stacks.  The fast one keeps kLdsStack entries per lane in LDS (one
@@ -91,66 +83,106 @@ struct DeepStack {
     RDR_DEV uint32_t pop() { return data[--sp]; }
 };
 
-// Any-hit over one mesh's BLAS in object space.  Stack entries are child codes.
-template <typename Stack>
-RDR_DEV bool blas_any_hit(const SceneView& sv, const GpuInstance& inst, vec3 o, vec3 d, float tmin, float tmax, Stack& st) {
-    const vec3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const BvhPair* pairs = sv.blas + inst.blas_root;
-    const int floor = st.sp;
-    st.push(0u);
-    while (st.sp > floor) {
-        const uint32_t code = st.pop();
-        if (!(code & kBvhLeaf)) {
-            visit_pair(pairs + code, o, inv_d, tmin, tmax, st);
-            continue;
-        }
-        const uint32_t count = (code >> 24) & 127u, first = code & 0xFFFFFFu;
-        const float* tp = sv.blas_tris + ((size_t)inst.tri_base + first) * 9;
-        for (uint32_t i = 0; i < count; ++i, tp += 9) {
-            if (ray_triangle(o, d, mk3(tp[0], tp[1], tp[2]), mk3(tp[3], tp[4], tp[5]), mk3(tp[6], tp[7], tp[8]), tmin, tmax)) {
-                st.sp = floor;
-                return true;
-            }
-        }
-    }
-    return false;
+struct Ray {
+    vec3 o, d, inv_d;
+};
+
+RDR_DEV Ray make_ray(vec3 o, vec3 d) {
+    Ray r;
+    r.o = o; r.d = d;
+    r.inv_d = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    return r;
 }
 
-template <typename Stack>
-RDR_DEV bool instance_any_hit(const SceneView& sv, uint32_t instance, vec3 o, vec3 d, float tmin, float tmax, Stack& st) {
-    const GpuInstance& inst = sv.instances[instance];
+// The ray in an instance's object space: origin and (unnormalised) direction through
+// the inverse model matrix, parameter t unchanged.
+RDR_DEV Ray object_ray(const GpuInstance& inst, vec3 o, vec3 d) {
     const float* iv = inst.inv;
     const vec3 oo = mk3(((iv[0] * o.x + iv[1] * o.y) + iv[2] * o.z) + iv[3], ((iv[4] * o.x + iv[5] * o.y) + iv[6] * o.z) + iv[7],
                         ((iv[8] * o.x + iv[9] * o.y) + iv[10] * o.z) + iv[11]);
     const vec3 od = mk3((iv[0] * d.x + iv[1] * d.y) + iv[2] * d.z, (iv[4] * d.x + iv[5] * d.y) + iv[6] * d.z,
                         (iv[8] * d.x + iv[9] * d.y) + iv[10] * d.z);
-    return blas_any_hit(sv, inst, oo, od, tmin, tmax, st);
+    return make_ray(oo, od);
 }
 
-// Is anything between the surface point and the sun?  The result is a plain "any
-// triangle hit", so the order instances are visited in is free: the pixel's own
-// instance, by far the likeliest occluder, goes first and is skipped afterwards.
+// Is anything between the surface point and the sun?  One loop walks both levels:
+// `cur` is the child code being processed, the stack holds the ones still to do, and
+// `floor` is the stack height at which the current instance's BLAS is exhausted.
+// The result is a plain "any triangle hit", so the visiting order is free: the
+// pixel's own instance, by far the likeliest occluder, goes first and is skipped
+// when the top level meets it again.
 template <typename Stack>
 RDR_DEV bool shadow_any_hit(const SceneView& sv, uint32_t own_instance, vec3 o, vec3 d, float tmin, float tmax, Stack& st) {
     st.sp = 0;
     st.overflow = false;
-    if (instance_any_hit(sv, own_instance, o, d, tmin, tmax, st)) return true;
-    const vec3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    st.push(0u);
-    while (st.sp > 0) {
-        const uint32_t code = st.pop();
-        if (!(code & kBvhLeaf)) {
-            visit_pair(sv.tlas + code, o, inv_d, tmin, tmax, st);
+    const Ray world = make_ray(o, d);
+    Ray ray = object_ray(sv.instances[own_instance], o, d);
+    uint32_t node_base = sv.instances[own_instance].blas_root, tri_base = sv.instances[own_instance].tri_base;
+    uint32_t cur = 0u; // node 0 of a tree holds the children of its root
+    bool in_blas = true, tlas_started = false;
+    int floor = 0;
+    for (;;) {
+        if (cur == kBvhNone) {
+            if (in_blas && st.sp == floor) { // this instance is done: back to the world ray
+                in_blas = false;
+                ray = world;
+                node_base = sv.tlas_base;
+                floor = 0;
+                if (!tlas_started) {
+                    tlas_started = true;
+                    cur = 0u;
+                    continue;
+                }
+            }
+            if (st.sp == 0) return false;
+            cur = st.pop();
+        }
+        if (!(cur & kBvhLeaf)) {
+            // one wide node: all its loads are in flight together
+            const uint4* q = reinterpret_cast<const uint4*>(sv.bvh + (node_base + cur));
+            uint32_t w[kBvhWidth * 4];
+#pragma unroll
+            for (int i = 0; i < kBvhWidth; ++i) {
+                const uint4 v = q[i];
+                w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+            }
+            cur = kBvhNone;
+#pragma unroll
+            for (int i = 0; i < kBvhWidth; ++i) {
+                const uint32_t code = w[i];
+                const uint32_t* bx = &w[kBvhWidth + 3 * i];
+                const bool h = code != kBvhNone && ray_box(half_lo(bx[0]), half_hi(bx[0]), half_lo(bx[1]), half_hi(bx[1]), half_lo(bx[2]),
+                                                           half_hi(bx[2]), ray.o, ray.inv_d, tmin, tmax);
+                if (h) {
+                    if (cur != kBvhNone) st.push(cur);
+                    cur = code;
+                }
+            }
             continue;
         }
-        const uint32_t count = (code >> 24) & 127u, first = code & 0xFFFFFFu;
-        for (uint32_t i = 0; i < count; ++i) {
-            const uint32_t instance = sv.tlas_items[first + i];
-            if (instance == own_instance) continue;
-            if (instance_any_hit(sv, instance, o, d, tmin, tmax, st)) return true;
+        const uint32_t count = (cur >> 24) & 127u, first = cur & 0xFFFFFFu;
+        if (in_blas) {
+            const float* tp = sv.blas_tris + (size_t)(tri_base + first) * 9;
+            for (uint32_t i = 0; i < count; ++i, tp += 9)
+                if (ray_triangle(ray.o, ray.d, mk3(tp[0], tp[1], tp[2]), mk3(tp[3], tp[4], tp[5]), mk3(tp[6], tp[7], tp[8]), tmin, tmax))
+                    return true;
+            cur = kBvhNone;
+            continue;
+        }
+        // top-level leaf: take its first instance now, leave the others on the stack
+        const uint32_t instance = sv.tlas_items[first];
+        if (count > 1u) st.push(kBvhLeaf | ((count - 1u) << 24) | (first + 1u));
+        cur = kBvhNone;
+        if (instance != own_instance) {
+            const GpuInstance& inst = sv.instances[instance];
+            ray = object_ray(inst, o, d);
+            node_base = inst.blas_root;
+            tri_base = inst.tri_base;
+            in_blas = true;
+            floor = st.sp;
+            cur = 0u;
         }
     }
-    return false;
 }
 
 // ---- barycentrics -----------------------------------------------------------------
