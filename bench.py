@@ -99,29 +99,19 @@ def main():
     stream = torch.cuda.current_stream()
     r.set_stream(stream.cuda_stream)  # kernels run on torch's stream: ordered with the collectives
 
-    n_inst = scene.meshlet_visibility_count
-    rows = [(H * k) // world for k in range(world + 1)]
+    frame = None
     if multi:
-        r.set_partition(n_inst * rank // world, n_inst * (rank + 1) // world)
-        r.set_shade_rows(rows[rank], rows[rank + 1])
-        vis = torch.as_tensor(r.visbuffer_device_array(), device="cuda")  # int64 view, zero copy
+        from renderer_amd.distributed import SortLastFrame
+        vis = torch.as_tensor(r.visbuffer_device_array(), device="cuda")  # int64 view of the keys, zero copy
         color = torch.as_tensor(r.color_device_array(), device="cuda")
         assert vis.data_ptr() == r.visbuffer_device_array().__cuda_array_interface__["data"][0]
-        even = all(rows[k + 1] - rows[k] == rows[1] for k in range(world))
+        frame = SortLastFrame(r, scene.meshlet_visibility_count, H, rank, world, vis, color)
 
     def step():
-        r.render_visbuffer()
-        if multi:
-            # keys never set bit 63, so MIN over int64 is the unsigned 64-bit min
-            dist.all_reduce(vis, op=dist.ReduceOp.MIN)
-        r.shade()
-        if multi:
-            mine = color[rows[rank]:rows[rank + 1]]
-            if even:
-                # in place: this rank's rows already sit at their offset of the output
-                dist.all_gather_into_tensor(color.view(-1), mine.reshape(-1))
-            else:
-                dist.all_gather([color[rows[k]:rows[k + 1]] for k in range(world)], mine.clone())
+        if frame is not None:
+            frame.step()  # raster own share -> u64-min all-reduce -> shade own rows -> all-gather
+        else:
+            r.render()
 
     for _ in range(args.warmup):
         step()

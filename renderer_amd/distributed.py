@@ -1,0 +1,61 @@
+"""Sort-last rendering across ranks (one process per GPU, torch.distributed; the "nccl" backend
+is RCCL on ROCm).
+
+The reference is single-GPU; this is the one step the path adds.  Every rank holds the whole
+scene, rasterises only its contiguous range of meshlet instances into a full-frame 64-bit
+visibility buffer, and the buffers are composited with one MIN all-reduce: min is associative
+and commutative and the clear value is its identity, so the result is bit-identical to the
+single-GPU buffer.  Keys never set bit 63, hence MIN over int64 (supported by every backend,
+gloo included) equals the unsigned 64-bit min.  Each rank then shades H/N rows and the RGBA8
+rows are all-gathered (half the bytes of gathering keys).
+"""
+import torch
+import torch.distributed as dist
+
+
+def instance_range(n_instances, rank, world):
+    """Contiguous share of the scene's meshlet instances for ``rank``."""
+    return (n_instances * rank) // world, (n_instances * (rank + 1)) // world
+
+
+def row_range(height, rank, world):
+    return (height * rank) // world, (height * (rank + 1)) // world
+
+
+def composite_min(vis_i64):
+    """In-place MIN all-reduce of a visibility buffer viewed as int64."""
+    assert vis_i64.dtype == torch.int64
+    dist.all_reduce(vis_i64, op=dist.ReduceOp.MIN)
+    return vis_i64
+
+
+def gather_rows(color, rank, world):
+    """All-gather the row strips each rank shaded into the full (H, W, 4) uint8 image, in place."""
+    height = color.shape[0]
+    bounds = [row_range(height, k, world) for k in range(world)]
+    sizes = {hi - lo for lo, hi in bounds}
+    lo, hi = bounds[rank]
+    if len(sizes) == 1:
+        # equal strips: this rank's rows already sit at their offset of the output buffer
+        dist.all_gather_into_tensor(color.view(-1), color[lo:hi].reshape(-1))
+    else:
+        dist.all_gather([color[a:b] for a, b in bounds], color[lo:hi].clone())
+    return color
+
+
+class SortLastFrame:
+    """One frame on ``world`` ranks around any renderer exposing set_partition /
+    set_shade_rows / render_visbuffer / shade (the HIP ``Renderer`` with device tensors, or the
+    CPU oracle with host tensors in the tests)."""
+
+    def __init__(self, renderer, n_instances, height, rank, world, vis_tensor, color_tensor):
+        self.r, self.rank, self.world = renderer, rank, world
+        self.vis, self.color = vis_tensor, color_tensor
+        renderer.set_partition(*instance_range(n_instances, rank, world))
+        renderer.set_shade_rows(*row_range(height, rank, world))
+
+    def step(self, camera=None, sun=None):
+        self.r.render_visbuffer(camera, sun)
+        composite_min(self.vis)
+        self.r.shade()
+        gather_rows(self.color, self.rank, self.world)
