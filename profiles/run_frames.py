@@ -9,7 +9,7 @@ frames = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 scene_name = sys.argv[2] if len(sys.argv) > 2 else "field"
 w, h = 3840, 2160
 scene = synth.make_field(1250, 5) if scene_name == "field" else synth.make_atrium(columns=10, spheres=60, sphere_subdiv=5)
-r = Renderer(w, h, RendererConfig(collect_stats=True))
+r = Renderer(w, h, RendererConfig(collect_stats=True, time_kernels=True))
 r.set_scene(scene)
 for _ in range(frames):
     r.render()

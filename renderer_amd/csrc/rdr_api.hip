@@ -74,6 +74,9 @@ struct rdr_renderer {
     DeviceBuffer<CullCommand> commands;
     DeviceBuffer<VisibleMeshlet> visible;
     DeviceBuffer<DeferredTriangle> deferred;
+    DeviceBuffer<SetupTri> setup;
+    DeviceBuffer<SetupMask> setup_mask;
+    DeviceBuffer<uint32_t> tile_count, tile_offset, tile_cursor, bin_entries;
     DeviceBuffer<uint32_t> resolve_out;
     DeviceBuffer<float> srgb_lut;
     DeviceBuffer<uint8_t> shadow;
@@ -314,12 +317,22 @@ FrameView make_frame_view(rdr_renderer* r) {
     fv.collect_stats = r->cfg.collect_stats;
     fv.shadow = r->shadow.ptr;
     fv.lds_stack_limit = r->lds_stack_limit;
+    fv.setup = r->setup.ptr;
+    fv.setup_mask = r->setup_mask.ptr;
+    fv.tile_count = r->tile_count.ptr;
+    fv.tile_offset = r->tile_offset.ptr;
+    fv.tile_cursor = r->tile_cursor.ptr;
+    fv.bin_entries = r->bin_entries.ptr;
+    fv.setup_capacity = (uint32_t)r->setup.count;
+    fv.bin_capacity = (uint32_t)r->bin_entries.count;
+    fv.tiles_x = (r->width + 63u) / 64u;
+    fv.tiles_y = (r->height + 63u) / 64u;
     fv.stat_slots = r->stat_slots.ptr;
     GridPlan& g = fv.grid;
     g.draw_blocks = std::max(1u, (r->sv.draw_count + 255u) / 256u);
     g.cull_blocks = std::max(1u, std::min((fv.command_capacity + 15u) / 16u, 1024u));
     g.raster_blocks = std::max(1u, std::min(fv.visible_capacity, 256u * 32u));
-    g.deferred_blocks = 2048;
+    g.deferred_blocks = fv.tiles_x * fv.tiles_y; // one workgroup per 64x64 tile
     g.shade_blocks_x = (r->width + 15u) / 16u;
     g.shade_blocks_y = (fv.row_hi - fv.row_lo + 15u) / 16u;
     g.slot_draw = 0;
@@ -334,7 +347,8 @@ FrameView make_frame_view(rdr_renderer* r) {
 int fetch_counters(rdr_renderer* r, FrameCounters* out) {
     RDR_HIP(hipStreamSynchronize(r->stream));
     RDR_HIP(hipMemcpy(out, r->counters.ptr, sizeof(FrameCounters), hipMemcpyDeviceToHost));
-    RDR_CHECK(out->deferred_overflow == 0, "frame: the deferred-triangle list overflowed; triangles were dropped");
+    RDR_CHECK(out->deferred_overflow == 0 && out->setup_overflow == 0 && out->bin_overflow == 0,
+              "frame: a tile-path list (deferred triangles, setup records or bins) overflowed; triangles were dropped");
     RDR_CHECK(out->cmd_count <= r->commands.count && out->vis_count <= r->visible.count, "frame: a work list overflowed");
     return 0;
 }
@@ -373,6 +387,11 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
     }
     const size_t npx = (size_t)width * height;
     if (r->vis.alloc(npx) || r->color.alloc(npx * 4) || r->counters.alloc(1) || r->shadow.alloc(npx)) return 1;
+    {
+        const size_t n_tiles = (size_t)((width + 63) / 64) * ((height + 63) / 64);
+        if (r->tile_count.alloc(n_tiles) || r->tile_offset.alloc(n_tiles) || r->tile_cursor.alloc(n_tiles)) return 1;
+        RDR_HIP(hipMemset(r->tile_count.ptr, 0, n_tiles * 4));
+    }
     RDR_HIP(hipMemset(r->counters.ptr, 0, sizeof(FrameCounters)));
     float lut[256];
     for (int i = 0; i < 256; ++i) {
@@ -454,7 +473,13 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
         if (r->instance_draw.upload(inst.data(), inst.size())) return 1;
     }
     if (r->commands.alloc(cmd_cap) || r->visible.alloc(vis_cap)) return 1;
-    if (r->deferred.alloc((size_t)std::min<uint64_t>(std::max<uint64_t>(tri_total, 1u << 16), 1u << 20))) return 1;
+    {
+        // tile path: deferred clip-space triangles, their screen-space records (clipping can fan one
+        // triangle into several) and the per-tile bins
+        const size_t n_def = (size_t)std::min<uint64_t>(std::max<uint64_t>(tri_total, 1u << 16), 1u << 21);
+        if (r->deferred.alloc(n_def) || r->setup.alloc(n_def + n_def / 2) || r->setup_mask.alloc(n_def + n_def / 2)) return 1;
+        if (r->bin_entries.alloc(std::max<size_t>(n_def * 4, (size_t)1 << 22))) return 1;
+    }
     {
         // statistics slots for the largest launch geometry this scene can produce
         r->sv.draw_count = s.draw_count;

@@ -21,9 +21,10 @@
 namespace {
 
 constexpr float kGuardBand = 8.0f;
-constexpr int kSmallExtent = 64 * 256;  // bounding boxes up to 64 px are scanned by one lane in int32
-constexpr int kLaneMaxPixels = 256;     // larger boxes go to the wave-cooperative path
-constexpr int kDeferExtent = 512 * 256; // bigger than this: the deferred (tile) path
+constexpr int kSmallExtent = 64 * 256; // bounding boxes up to 64 px on a side are candidates for the per-lane scan (int32 exact)
+constexpr int kLaneMaxPixels = 512;    // ... if they hold at most this many pixels; everything else goes to the tile path
+constexpr int kTile = 64;              // screen tile of the binned path, pixels
+constexpr int kTileBatch = 64;         // triangle records staged in LDS per round
 
 // ------------------------------------------------------------------------------
 // Draw cull
@@ -365,26 +366,6 @@ RDR_DEV uint32_t scan_lane(const SceneView& sv, const FrameView& fv, const TriSe
     return frags;
 }
 
-// All 64 lanes scan one triangle: 8x8 pixel blocks swept over the bounding box.
-// `t` and `id` must be wave-uniform.
-template <typename I>
-RDR_DEV uint32_t scan_wave(const SceneView& sv, const FrameView& fv, const TriSetup<I>& t, const AlphaTest& at,
-                           uint32_t id, uint32_t lane) {
-    uint32_t frags = 0;
-    const int lx = (int)(lane & 7u), ly = (int)(lane >> 3);
-    for (int by = t.py0 & ~7; by <= t.py1; by += 8) {
-        const int py = by + ly;
-        for (int bx = t.px0 & ~7; bx <= t.px1; bx += 8) {
-            const int px = bx + lx;
-            if (px < t.px0 || px > t.px1 || py < t.py0 || py > t.py1) continue;
-            I e01, e12, e20;
-            edges_at<I>(t, px, py, e01, e12, e20);
-            frags += shade_sample<I>(sv, fv, t, at, px, py, e01, e12, e20, id);
-        }
-    }
-    return frags;
-}
-
 // Per-wave LDS: the transformed vertices of one meshlet.
 struct MeshletLds {
     float cx[64], cy[64], cz[64], cw[64]; // clip space
@@ -430,10 +411,7 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
 
         for (uint32_t t0 = 0; t0 < m.triangle_count; t0 += 64) {
             const uint32_t ti = t0 + lane;
-            // 0 = nothing, 1 = wave-cooperative, 2 = deferred
-            uint32_t route = 0;
-            TriSetup<int32_t> ts;
-            ts.valid = false;
+            bool defer = false; // clipped, large or pixel-heavy triangles go to the tile path
             uint32_t ia = 0, ib = 0, ic = 0;
             if (ti < m.triangle_count) {
                 const uint8_t* tp = sv.meshlet_triangles + m.triangle_offset + ti * 3;
@@ -450,16 +428,14 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
                 culled = culled && (lds.cw[ia] > 0.0f && lds.cw[ib] > 0.0f && lds.cw[ic] > 0.0f);
                 if (!culled) {
                     st_raster++;
-                    if (lds.clip[ia] | lds.clip[ib] | lds.clip[ic]) {
-                        route = 2;
-                    } else {
+                    defer = (lds.clip[ia] | lds.clip[ib] | lds.clip[ic]) != 0u;
+                    if (!defer) {
                         const int32_t X0 = lds.X[ia], X1 = lds.X[ib], X2 = lds.X[ic];
                         const int32_t Y0 = lds.Y[ia], Y1 = lds.Y[ib], Y2 = lds.Y[ic];
                         const int32_t ex = max(X0, max(X1, X2)) - min(X0, min(X1, X2));
                         const int32_t ey = max(Y0, max(Y1, Y2)) - min(Y0, min(Y1, Y2));
-                        if (ex > kDeferExtent || ey > kDeferExtent) {
-                            route = 2;
-                        } else {
+                        defer = ex > kSmallExtent || ey > kSmallExtent;
+                        if (!defer) {
                             SnapVert s0, s1, s2;
                             s0.X = X0; s0.Y = Y0; s0.z = lds.cz[ia] / lds.cw[ia];
                             s1.X = X1; s1.Y = Y1; s1.z = lds.cz[ib] / lds.cw[ib];
@@ -468,7 +444,7 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
                             s0.u0 = s0.v0 = s0.u1 = s0.v1 = 0.0f;
                             s1.u0 = s1.v0 = s1.u1 = s1.v1 = 0.0f;
                             s2.u0 = s2.v0 = s2.u1 = s2.v1 = 0.0f;
-                            if (at.enabled && at.has_tex) {
+                            if (at.enabled && at.has_tex) { // the alpha test needs perspective-correct uv
                                 const uint32_t* mv = sv.meshlet_vertices + m.vertex_offset;
                                 const rdr_vertex* va = &sv.vertices[mv[ia] + mesh_vertex_offset];
                                 const rdr_vertex* vb = &sv.vertices[mv[ib] + mesh_vertex_offset];
@@ -478,15 +454,11 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
                                 s1.u0 = vb->uv[0]; s1.v0 = vb->uv[1]; s1.u1 = vb->uv[2]; s1.v1 = vb->uv[3];
                                 s2.u0 = vc->uv[0]; s2.v0 = vc->uv[1]; s2.u1 = vc->uv[2]; s2.v1 = vc->uv[3];
                             }
-                            if (ex <= kSmallExtent && ey <= kSmallExtent) {
-                                ts = setup_triangle<int32_t>(fv, s0, s1, s2, cull_front);
-                                if (ts.valid) {
-                                    const int npx = (ts.px1 - ts.px0 + 1) * (ts.py1 - ts.py0 + 1);
-                                    if (npx > kLaneMaxPixels) route = 1;
-                                    else st_frags += scan_lane<int32_t>(sv, fv, ts, at, (vm.instance << 7) | ti);
-                                }
-                            } else {
-                                route = 3; // medium: wave-cooperative in 64-bit
+                            const TriSetup<int32_t> ts = setup_triangle<int32_t>(fv, s0, s1, s2, cull_front);
+                            if (ts.valid) {
+                                const int npx = (ts.px1 - ts.px0 + 1) * (ts.py1 - ts.py0 + 1);
+                                defer = npx > kLaneMaxPixels;
+                                if (!defer) st_frags += scan_lane<int32_t>(sv, fv, ts, at, (vm.instance << 7) | ti);
                             }
                         }
                     }
@@ -494,13 +466,13 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
             }
             // deferred triangles: reserve slots with one atomic per wave
             {
-                const unsigned long long dm = __ballot(route == 2);
+                const unsigned long long dm = __ballot(defer);
                 if (dm) {
                     const uint32_t n = (uint32_t)__popcll(dm);
                     uint32_t base = 0;
                     if (lane == (uint32_t)__ffsll((long long)dm) - 1u) base = atomicAdd(&fv.counters->deferred_count, n);
                     base = __shfl(base, __ffsll((long long)dm) - 1, 64);
-                    if (route == 2) {
+                    if (defer) {
                         const uint32_t slot = base + ballot_rank(dm);
                         if (slot < fv.deferred_capacity) {
                             DeferredTriangle* dt = &fv.deferred[slot];
@@ -524,35 +496,6 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
                     }
                 }
             }
-            // wave-cooperative triangles, one at a time, parameters broadcast from the owner lane
-            unsigned long long wm = __ballot(route == 1 || route == 3);
-            while (wm) {
-                const int src = __ffsll((long long)wm) - 1;
-                wm &= wm - 1;
-                const uint32_t sti = t0 + (uint32_t)src;
-                const uint8_t* tp = sv.meshlet_triangles + m.triangle_offset + sti * 3;
-                const uint32_t ja = tp[0], jb = tp[1], jc = tp[2];
-                SnapVert s0, s1, s2;
-                s0.X = lds.X[ja]; s0.Y = lds.Y[ja]; s0.z = lds.cz[ja] / lds.cw[ja];
-                s1.X = lds.X[jb]; s1.Y = lds.Y[jb]; s1.z = lds.cz[jb] / lds.cw[jb];
-                s2.X = lds.X[jc]; s2.Y = lds.Y[jc]; s2.z = lds.cz[jc] / lds.cw[jc];
-                s0.inv_w = s1.inv_w = s2.inv_w = 0.0f;
-                s0.u0 = s0.v0 = s0.u1 = s0.v1 = 0.0f;
-                s1.u0 = s1.v0 = s1.u1 = s1.v1 = 0.0f;
-                s2.u0 = s2.v0 = s2.u1 = s2.v1 = 0.0f;
-                if (at.enabled && at.has_tex) {
-                    const uint32_t* mv = sv.meshlet_vertices + m.vertex_offset;
-                    const rdr_vertex* va = &sv.vertices[mv[ja] + mesh_vertex_offset];
-                    const rdr_vertex* vb = &sv.vertices[mv[jb] + mesh_vertex_offset];
-                    const rdr_vertex* vc = &sv.vertices[mv[jc] + mesh_vertex_offset];
-                    s0.inv_w = 1.0f / lds.cw[ja]; s1.inv_w = 1.0f / lds.cw[jb]; s2.inv_w = 1.0f / lds.cw[jc];
-                    s0.u0 = va->uv[0]; s0.v0 = va->uv[1]; s0.u1 = va->uv[2]; s0.v1 = va->uv[3];
-                    s1.u0 = vb->uv[0]; s1.v0 = vb->uv[1]; s1.u1 = vb->uv[2]; s1.v1 = vb->uv[3];
-                    s2.u0 = vc->uv[0]; s2.v0 = vc->uv[1]; s2.u1 = vc->uv[2]; s2.v1 = vc->uv[3];
-                }
-                const TriSetup<long long> tw = setup_triangle<long long>(fv, s0, s1, s2, cull_front);
-                if (tw.valid) st_frags += scan_wave<long long>(sv, fv, tw, at, (vm.instance << 7) | sti, lane);
-            }
         }
     }
     if (fv.collect_stats) {
@@ -566,7 +509,7 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
 }
 
 // ------------------------------------------------------------------------------
-// Deferred triangles: clip in clip space, then scan with the whole wave.
+// Clipping helpers of the tile path.
 // ------------------------------------------------------------------------------
 struct ClipVert {
     float x, y, z, w, uv[4];
@@ -604,24 +547,102 @@ RDR_DEV SnapVert snap_clip_vert(const ClipVert& v, float half_w, float half_h) {
     return s;
 }
 
-__global__ __launch_bounds__(64) void k_deferred(SceneView sv, FrameView fv) {
-    __shared__ ClipVert poly[12];
-    __shared__ ClipVert tmp[12];
-    __shared__ int n_shared;
-    const uint32_t lane = threadIdx.x;
+// ------------------------------------------------------------------------------
+// Tile path: clipped, large or pixel-heavy triangles.
+//   k_tile_setup  clip -> fan -> snap -> SetupTri records, count triangles per 64x64 tile
+//   k_tile_scan   prefix sum of the per-tile counts -> bin offsets
+//   k_tile_fill   write each record's index into the bins of the tiles it touches
+//   k_tile_raster one workgroup per tile: bins staged through LDS in batches, each
+//                 thread owns a 4x4 pixel block whose 16 keys stay in registers, then
+//                 one read-min-write of the tile (no atomics: the tile has one owner
+//                 and the per-meshlet rasteriser has finished).
+// ------------------------------------------------------------------------------
+
+struct EdgeEq {
+    long long e;  // value at the reference pixel centre
+    long long ax; // change per pixel in x
+    long long by; // change per pixel in y
+    int bias;     // 0 for top-left edges, -1 otherwise
+};
+
+RDR_DEV EdgeEq make_edge(int32_t Xa, int32_t Ya, int32_t Xb, int32_t Yb, int px, int py) {
+    const int32_t dx = Xb - Xa, dy = Yb - Ya;
+    EdgeEq q;
+    const long long Px = (long long)px * 256 + 128, Py = (long long)py * 256 + 128;
+    q.e = (long long)dx * (Py - Ya) - (long long)dy * (Px - Xa);
+    q.ax = -(long long)dy * 256;
+    q.by = (long long)dx * 256;
+    q.bias = (dy < 0 || (dy == 0 && dx > 0)) ? 0 : -1;
+    return q;
+}
+
+// Largest value of the edge function over the pixel box [0,w] x [0,h] from the reference pixel.
+RDR_DEV long long edge_max(const EdgeEq& q, int w, int h) {
+    return q.e + (q.ax > 0 ? q.ax * w : 0) + (q.by > 0 ? q.by * h : 0);
+}
+
+// Does the triangle possibly cover a pixel centre of tile (tx, ty)?  Box test plus the
+// three edges evaluated at their most favourable tile corner.  Deterministic: the
+// counting and the filling kernel must agree.
+RDR_DEV bool tile_touched(const SetupTri& t, uint32_t tx, uint32_t ty) {
+    const int x0 = (int)tx * kTile, y0 = (int)ty * kTile;
+    if ((int)t.px1 < x0 || (int)t.px0 > x0 + kTile - 1 || (int)t.py1 < y0 || (int)t.py0 > y0 + kTile - 1) return false;
+    const EdgeEq e01 = make_edge(t.X0, t.Y0, t.X1, t.Y1, x0, y0);
+    const EdgeEq e12 = make_edge(t.X1, t.Y1, t.X2, t.Y2, x0, y0);
+    const EdgeEq e20 = make_edge(t.X2, t.Y2, t.X0, t.Y0, x0, y0);
+    return edge_max(e01, kTile - 1, kTile - 1) + e01.bias >= 0 && edge_max(e12, kTile - 1, kTile - 1) + e12.bias >= 0 &&
+           edge_max(e20, kTile - 1, kTile - 1) + e20.bias >= 0;
+}
+
+// Orient, face-cull and box a snapped triangle. Returns false when nothing can be covered.
+RDR_DEV bool make_setup(const FrameView& fv, SnapVert v0, SnapVert v1, SnapVert v2, bool cull_front, SetupTri& t, SetupMask& mk) {
+    long long A = (long long)(v1.X - v0.X) * (v2.Y - v0.Y) - (long long)(v1.Y - v0.Y) * (v2.X - v0.X);
+    if (A == 0) return false;
+    if (A > 0) {
+        if (cull_front) return false; // clockwise on the y-down screen: front-facing, culled in the opaque pipeline
+    } else {
+        const SnapVert tmp = v1; v1 = v2; v2 = tmp;
+        A = -A;
+    }
+    const int32_t minX = min(v0.X, min(v1.X, v2.X)), maxX = max(v0.X, max(v1.X, v2.X));
+    const int32_t minY = min(v0.Y, min(v1.Y, v2.Y)), maxY = max(v0.Y, max(v1.Y, v2.Y));
+    const int px0 = max((minX - 128 + 255) >> 8, 0), px1 = min((maxX - 128) >> 8, (int)fv.width - 1);
+    const int py0 = max((minY - 128 + 255) >> 8, 0), py1 = min((maxY - 128) >> 8, (int)fv.height - 1);
+    if (px0 > px1 || py0 > py1) return false;
+    t.X0 = v0.X; t.Y0 = v0.Y; t.X1 = v1.X; t.Y1 = v1.Y; t.X2 = v2.X; t.Y2 = v2.Y;
+    t.z0 = v0.z; t.dz1 = v1.z - v0.z; t.dz2 = v2.z - v0.z;
+    t.inv_area = 1.0f / (float)A;
+    t.px0 = (uint16_t)px0; t.py0 = (uint16_t)py0; t.px1 = (uint16_t)px1; t.py1 = (uint16_t)py1;
+    t._pad = 0;
+    mk.inv_w[0] = v0.inv_w; mk.inv_w[1] = v1.inv_w; mk.inv_w[2] = v2.inv_w;
+    const SnapVert* vs[3] = {&v0, &v1, &v2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { mk.uv[k][0] = vs[k]->u0; mk.uv[k][1] = vs[k]->v0; mk.uv[k][2] = vs[k]->u1; mk.uv[k][3] = vs[k]->v1; }
+    mk._pad = 0;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_tile_setup(SceneView sv, FrameView fv) {
+    const uint32_t lane = lane_id();
     const uint32_t count = min(fv.counters->deferred_count, fv.deferred_capacity);
     const float half_w = (float)fv.width * 0.5f, half_h = (float)fv.height * 0.5f;
-    uint32_t st_frags = 0;
-    for (uint32_t di = blockIdx.x; di < count; di += gridDim.x) {
-        const DeferredTriangle* dt = &fv.deferred[di];
-        const rdr_mesh_draw d = sv.draws[dt->draw_id];
-        const AlphaTest at = make_alpha_test(sv, d);
-        const bool cull_front = d.alpha_mode == 0u;
-        const uint32_t id = dt->id;
-        __syncthreads();
-        if (lane == 0) {
-            // Sutherland-Hodgman against near + the four guard-band planes (serial, tiny)
-            int n = 3;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    // whole waves iterate together so that slots can be reserved with one atomic per wave
+    for (uint32_t base_i = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base_i < count; base_i += stride) {
+        const uint32_t di = base_i + lane;
+        ClipVert poly[10], tmp[10];
+        int n = 0;
+        bool cull_front = true, masked = false;
+        uint32_t id = 0, draw_id = 0;
+        if (di < count) {
+            const DeferredTriangle* dt = &fv.deferred[di];
+            draw_id = dt->draw_id;
+            id = dt->id;
+            const rdr_mesh_draw d = sv.draws[draw_id];
+            cull_front = d.alpha_mode == 0u;
+            const AlphaTest at = make_alpha_test(sv, d);
+            masked = at.enabled && at.has_tex;
+            n = 3;
             for (int k = 0; k < 3; ++k) {
                 poly[k].x = dt->pos[k][0]; poly[k].y = dt->pos[k][1]; poly[k].z = dt->pos[k][2]; poly[k].w = dt->pos[k][3];
                 for (int j = 0; j < 4; ++j) poly[k].uv[j] = dt->uv[k][j];
@@ -630,6 +651,7 @@ __global__ __launch_bounds__(64) void k_deferred(SceneView sv, FrameView fv) {
                                vert_needs_clip(poly[1].x, poly[1].y, poly[1].z, poly[1].w) ||
                                vert_needs_clip(poly[2].x, poly[2].y, poly[2].z, poly[2].w);
             if (needs) {
+                // Sutherland-Hodgman against near + the four guard-band planes
                 for (int plane = 0; plane < 5 && n > 0; ++plane) {
                     int mcount = 0;
                     for (int i = 0; i < n; ++i) {
@@ -645,28 +667,198 @@ __global__ __launch_bounds__(64) void k_deferred(SceneView sv, FrameView fv) {
                     n = mcount;
                 }
             }
-            n_shared = n;
         }
-        __syncthreads();
-        const int n = n_shared;
-        if (n < 3) continue;
-        const SnapVert s0 = snap_clip_vert(poly[0], half_w, half_h);
-        SnapVert sp = snap_clip_vert(poly[1], half_w, half_h);
-        for (int i = 2; i < n; ++i) {
-            const SnapVert sn = snap_clip_vert(poly[i], half_w, half_h);
-            const TriSetup<long long> tw = setup_triangle<long long>(fv, s0, sp, sn, cull_front);
-            if (tw.valid) st_frags += scan_wave<long long>(sv, fv, tw, at, id, lane);
-            sp = sn;
+        const int max_n = (int)__reduce_max_sync(~0ull, n);
+        SnapVert s0{}, sp{};
+        if (n >= 3) {
+            s0 = snap_clip_vert(poly[0], half_w, half_h);
+            sp = snap_clip_vert(poly[1], half_w, half_h);
         }
-    }
-    if (fv.collect_stats) {
-        const uint32_t f = wave_sum(st_frags);
-        if (lane == 0) fv.stat_slots[fv.grid.slot_deferred + blockIdx.x] = f;
+        for (int i = 2; i < max_n; ++i) { // fan triangle (0, i-1, i), the same i in every lane
+            SetupTri t;
+            SetupMask mk;
+            bool ok = false;
+            if (i < n) {
+                const SnapVert sn = snap_clip_vert(poly[i], half_w, half_h);
+                ok = make_setup(fv, s0, sp, sn, cull_front, t, mk);
+                sp = sn;
+            }
+            const unsigned long long m = __ballot(ok);
+            if (!m) continue;
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t slot0 = 0;
+            if ((int)lane == leader) slot0 = atomicAdd(&fv.counters->setup_count, (uint32_t)__popcll(m));
+            slot0 = __shfl(slot0, leader, 64);
+            if (!ok) continue;
+            const uint32_t slot = slot0 + ballot_rank(m);
+            if (slot >= fv.setup_capacity) {
+                atomicAdd(&fv.counters->setup_overflow, 1u);
+                continue;
+            }
+            t.id = id; t.draw_id = draw_id; t.masked = masked ? 1u : 0u;
+            fv.setup[slot] = t;
+            if (masked) fv.setup_mask[slot] = mk;
+            for (uint32_t ty = t.py0 / kTile; ty <= t.py1 / kTile; ++ty)
+                for (uint32_t tx = t.px0 / kTile; tx <= t.px1 / kTile; ++tx)
+                    if (tile_touched(t, tx, ty)) atomicAdd(&fv.tile_count[ty * fv.tiles_x + tx], 1u);
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void k_clear(unsigned long long* vis, size_t n, FrameCounters* counters) {
-    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+__global__ __launch_bounds__(1024) void k_tile_scan(FrameView fv) {
+    __shared__ uint32_t partial[1024];
+    const uint32_t n_tiles = fv.tiles_x * fv.tiles_y;
+    const uint32_t per = (n_tiles + 1023u) / 1024u;
+    const uint32_t first = threadIdx.x * per, last = min(first + per, n_tiles);
+    uint32_t sum = 0;
+    for (uint32_t i = first; i < last; ++i) sum += fv.tile_count[i];
+    partial[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) { // inclusive Hillis-Steele scan
+        const uint32_t v = threadIdx.x >= o ? partial[threadIdx.x - o] : 0u;
+        __syncthreads();
+        partial[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = partial[threadIdx.x] - sum;
+    for (uint32_t i = first; i < last; ++i) {
+        fv.tile_offset[i] = run;
+        fv.tile_cursor[i] = 0u;
+        run += fv.tile_count[i];
+    }
+    if (threadIdx.x == 1023) {
+        fv.counters->bin_total = partial[1023];
+        if (partial[1023] > fv.bin_capacity) fv.counters->bin_overflow = 1u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tile_fill(FrameView fv) {
+    const uint32_t count = min(fv.counters->setup_count, fv.setup_capacity);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const SetupTri t = fv.setup[i];
+        for (uint32_t ty = t.py0 / kTile; ty <= t.py1 / kTile; ++ty)
+            for (uint32_t tx = t.px0 / kTile; tx <= t.px1 / kTile; ++tx)
+                if (tile_touched(t, tx, ty)) {
+                    const uint32_t tile = ty * fv.tiles_x + tx;
+                    const uint32_t slot = fv.tile_offset[tile] + atomicAdd(&fv.tile_cursor[tile], 1u);
+                    if (slot < fv.bin_capacity) fv.bin_entries[slot] = i;
+                }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tile_raster(SceneView sv, FrameView fv) {
+    __shared__ SetupTri batch[kTileBatch];
+    __shared__ uint32_t batch_index[kTileBatch];
+    __shared__ uint32_t wg_frags[4];
+    const uint32_t tile = blockIdx.x;
+    const uint32_t n_all = fv.tile_count[tile];
+    const uint32_t off = fv.tile_offset[tile];
+    const uint32_t n = off >= fv.bin_capacity ? 0u : min(n_all, fv.bin_capacity - off);
+    uint32_t frags = 0;
+    if (n) {
+        const int tile_x0 = (int)(tile % fv.tiles_x) * kTile, tile_y0 = (int)(tile / fv.tiles_x) * kTile;
+        // this thread's 4x4 pixel block
+        const int bx0 = tile_x0 + (int)(threadIdx.x & 15u) * 4, by0 = tile_y0 + (int)(threadIdx.x >> 4) * 4;
+        const bool block_on_screen = bx0 < (int)fv.width && by0 < (int)fv.height;
+        unsigned long long keys[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) keys[k] = RDR_VIS_CLEAR;
+
+        for (uint32_t b0 = 0; b0 < n; b0 += kTileBatch) {
+            const uint32_t nb = min((uint32_t)kTileBatch, n - b0);
+            __syncthreads(); // the previous batch has been consumed
+            {   // stage the batch: 4 threads per 64-byte record, coalesced 16-byte loads
+                const uint32_t r = threadIdx.x >> 2, part = threadIdx.x & 3u;
+                if (r < nb) {
+                    const uint32_t idx = fv.bin_entries[off + b0 + r];
+                    reinterpret_cast<uint4*>(&batch[r])[part] = reinterpret_cast<const uint4*>(&fv.setup[idx])[part];
+                    if (part == 0) batch_index[r] = idx;
+                }
+            }
+            __syncthreads();
+            if (!block_on_screen) continue;
+            for (uint32_t k = 0; k < nb; ++k) {
+                const SetupTri& t = batch[k];
+                if ((int)t.px1 < bx0 || (int)t.px0 > bx0 + 3 || (int)t.py1 < by0 || (int)t.py0 > by0 + 3) continue;
+                const EdgeEq e01 = make_edge(t.X0, t.Y0, t.X1, t.Y1, bx0, by0); // weight of v2
+                const EdgeEq e12 = make_edge(t.X1, t.Y1, t.X2, t.Y2, bx0, by0); // weight of v0
+                const EdgeEq e20 = make_edge(t.X2, t.Y2, t.X0, t.Y0, bx0, by0); // weight of v1
+                if (edge_max(e01, 3, 3) + e01.bias < 0 || edge_max(e12, 3, 3) + e12.bias < 0 || edge_max(e20, 3, 3) + e20.bias < 0) continue;
+                AlphaTest at;
+                at.enabled = false;
+                const SetupMask* mk = nullptr;
+                if (sv.draws[t.draw_id].alpha_mode == 1u) {
+                    at = make_alpha_test(sv, sv.draws[t.draw_id]);
+                    if (t.masked) mk = &fv.setup_mask[batch_index[k]];
+                }
+                const float z0 = t.z0, dz1 = t.dz1, dz2 = t.dz2, inv_area = t.inv_area;
+                const uint32_t id = t.id;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const long long v01 = e01.e + e01.ax * i + e01.by * j;
+                        const long long v12 = e12.e + e12.ax * i + e12.by * j;
+                        const long long v20 = e20.e + e20.ax * i + e20.by * j;
+                        if (((v01 + e01.bias) | (v12 + e12.bias) | (v20 + e20.bias)) < 0) continue;
+                        if (bx0 + i >= (int)fv.width || by0 + j >= (int)fv.height) continue;
+                        if (at.enabled) {
+                            float alpha = 1.0f;
+                            if (at.has_tex && mk) {
+                                SnapVert a{}, b{}, c{};
+                                a.inv_w = mk->inv_w[0]; b.inv_w = mk->inv_w[1]; c.inv_w = mk->inv_w[2];
+                                a.u0 = mk->uv[0][0]; a.v0 = mk->uv[0][1]; a.u1 = mk->uv[0][2]; a.v1 = mk->uv[0][3];
+                                b.u0 = mk->uv[1][0]; b.v0 = mk->uv[1][1]; b.u1 = mk->uv[1][2]; b.v1 = mk->uv[1][3];
+                                c.u0 = mk->uv[2][0]; c.v0 = mk->uv[2][1]; c.u1 = mk->uv[2][2]; c.v1 = mk->uv[2][3];
+                                float u, v, ux, vx, uy, vy;
+                                persp_uv<long long>(a, b, c, v12, v20, v01, at.uv_set, u, v);
+                                persp_uv<long long>(a, b, c, v12 + e12.ax, v20 + e20.ax, v01 + e01.ax, at.uv_set, ux, vx);
+                                persp_uv<long long>(a, b, c, v12 + e12.by, v20 + e20.by, v01 + e01.by, at.uv_set, uy, vy);
+                                u = u * at.sx + at.ox; v = v * at.sy + at.oy;
+                                ux = ux * at.sx + at.ox; vx = vx * at.sy + at.oy;
+                                uy = uy * at.sx + at.ox; vy = vy * at.sy + at.oy;
+                                alpha = image_sample_grad(sv.images[at.image], sv.texels, sv.srgb_lut, u, v, ux - u, vx - v, uy - u, vy - v).w;
+                            }
+                            alpha = alpha * at.factor_a;
+                            if (alpha < at.cutoff) continue;
+                        }
+                        const float l1 = (float)v20 * inv_area, l2 = (float)v01 * inv_area;
+                        const float z = clampf(fmaf(l2, dz2, fmaf(l1, dz1, z0)), 0.0f, 1.0f);
+                        const unsigned long long key = ((unsigned long long)(0x7FFFFFFFu - __float_as_uint(z)) << 32) | (unsigned long long)id;
+                        keys[j * 4 + i] = min(keys[j * 4 + i], key);
+                        frags++;
+                    }
+                }
+            }
+        }
+        // merge the block into the visibility buffer: rows of 4 keys, 32 contiguous bytes each
+        if (block_on_screen) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (by0 + j >= (int)fv.height) continue;
+                unsigned long long* row = fv.vis + (size_t)(by0 + j) * fv.width + bx0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (bx0 + i >= (int)fv.width) continue;
+                    const unsigned long long k = keys[j * 4 + i];
+                    if (k != RDR_VIS_CLEAR && k < row[i]) row[i] = k;
+                }
+            }
+        }
+    }
+    if (fv.collect_stats) {
+        const uint32_t f = wave_sum(frags);
+        if ((threadIdx.x & 63u) == 0) wg_frags[threadIdx.x >> 6] = f;
+        __syncthreads();
+        if (threadIdx.x == 0) fv.stat_slots[fv.grid.slot_deferred + blockIdx.x] = wg_frags[0] + wg_frags[1] + wg_frags[2] + wg_frags[3];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_clear(unsigned long long* vis, size_t n, FrameCounters* counters, uint32_t* tile_count,
+                                               uint32_t n_tiles) {
+    const size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi < n_tiles) tile_count[gi] = 0u;
+    const size_t i = gi * 2;
     if (i + 1 < n) {
         *reinterpret_cast<ulonglong2*>(vis + i) = make_ulonglong2(RDR_VIS_CLEAR, RDR_VIS_CLEAR);
     } else if (i < n) {
@@ -699,7 +891,7 @@ int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t st
     const size_t npx = (size_t)fv.width * fv.height;
     const uint32_t clear_blocks = (uint32_t)((npx / 2 + 1 + 255) / 256);
     if (ev) RDR_HIP(hipEventRecord(ev[0], stream));
-    hipLaunchKernelGGL(k_clear, dim3(clear_blocks), dim3(256), 0, stream, fv.vis, npx, fv.counters);
+    hipLaunchKernelGGL(k_clear, dim3(clear_blocks), dim3(256), 0, stream, fv.vis, npx, fv.counters, fv.tile_count, fv.tiles_x * fv.tiles_y);
     if (ev) RDR_HIP(hipEventRecord(ev[1], stream));
     if (sv.draw_count) {
         hipLaunchKernelGGL(k_draw_cull, dim3(fv.grid.draw_blocks), dim3(256), 0, stream, sv, fv);
@@ -709,7 +901,10 @@ int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t st
         if (ev) RDR_HIP(hipEventRecord(ev[3], stream));
         hipLaunchKernelGGL(k_raster, dim3(fv.grid.raster_blocks), dim3(64), 0, stream, sv, fv);
         if (ev) RDR_HIP(hipEventRecord(ev[4], stream));
-        hipLaunchKernelGGL(k_deferred, dim3(fv.grid.deferred_blocks), dim3(64), 0, stream, sv, fv);
+        hipLaunchKernelGGL(k_tile_setup, dim3(256), dim3(256), 0, stream, sv, fv);
+        hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, fv);
+        hipLaunchKernelGGL(k_tile_fill, dim3(256), dim3(256), 0, stream, fv);
+        hipLaunchKernelGGL(k_tile_raster, dim3(fv.grid.deferred_blocks), dim3(256), 0, stream, sv, fv);
         if (ev) RDR_HIP(hipEventRecord(ev[5], stream));
     }
     RDR_HIP(hipGetLastError());

@@ -59,6 +59,25 @@ struct DeferredTriangle {
 };
 static_assert(sizeof(DeferredTriangle) == 112, "DeferredTriangle layout");
 
+// A screen-space triangle ready for the tile rasteriser: snapped vertices already
+// oriented so that the interior has positive edge values.
+struct SetupTri {
+    int32_t X0, Y0, X1, Y1, X2, Y2; // 24.8 fixed point, y down
+    float z0, dz1, dz2, inv_area;
+    uint32_t id;
+    uint32_t draw_id;
+    uint16_t px0, py0, px1, py1; // covered pixel box, clamped to the screen
+    uint32_t masked;             // alpha-tested draw with a texture: SetupMask holds uv
+    uint32_t _pad;
+};
+static_assert(sizeof(SetupTri) == 64, "SetupTri layout");
+struct SetupMask {
+    float inv_w[3];
+    float uv[3][4];
+    uint32_t _pad;
+};
+static_assert(sizeof(SetupMask) == 64, "SetupMask layout");
+
 // Heads of the per-frame work lists.
 struct FrameCounters {
     uint32_t cmd_count;
@@ -66,7 +85,11 @@ struct FrameCounters {
     uint32_t deferred_count;
     uint32_t deferred_overflow;
     uint32_t shadow_overflow; // pixels k_shadow left to k_shadow_deep
-    uint32_t _pad0[11];
+    uint32_t setup_count;     // SetupTri records written this frame
+    uint32_t setup_overflow;
+    uint32_t bin_total;       // tile-bin entries needed this frame
+    uint32_t bin_overflow;
+    uint32_t _pad0[7];
     unsigned long long _pad1[16];
 };
 static_assert(sizeof(FrameCounters) == 192, "FrameCounters layout");
@@ -168,6 +191,13 @@ struct FrameView {
     uint32_t command_capacity, visible_capacity, deferred_capacity;
     uint32_t collect_stats;
     uint8_t* shadow; // one byte per pixel: 1 = the sun ray is blocked
+    SetupTri* setup;
+    SetupMask* setup_mask;
+    uint32_t* tile_count;  // per tile: triangles binned
+    uint32_t* tile_offset; // per tile: first entry in bin_entries
+    uint32_t* tile_cursor; // per tile: fill cursor
+    uint32_t* bin_entries; // SetupTri indices grouped by tile
+    uint32_t setup_capacity, bin_capacity, tiles_x, tiles_y;
     uint32_t lds_stack_limit; // entries of the LDS traversal stack in use (<= 24; lowered only by tests)
     // Per-workgroup statistics: every workgroup stores its partial counts in its own
     // slot with plain stores (no contended atomics); the host sums the slots on request.
