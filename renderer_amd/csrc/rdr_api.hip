@@ -113,6 +113,7 @@ struct rdr_renderer {
     uint32_t row_lo = 0, row_hi = 0xFFFFFFFFu;
     uint32_t meshlet_visibility_count = 0;
     uint32_t lds_stack_limit = 24;
+    uint32_t masked_meshlets = 0; // LOD0 meshlet instances of alpha-masked draws
     rdr_stats stats{};
 };
 
@@ -332,13 +333,14 @@ FrameView make_frame_view(rdr_renderer* r) {
     g.draw_blocks = std::max(1u, (r->sv.draw_count + 255u) / 256u);
     g.cull_blocks = std::max(1u, std::min((fv.command_capacity + 15u) / 16u, 1024u));
     g.raster_blocks = std::max(1u, std::min(fv.visible_capacity, 256u * 32u));
+    g.raster_mask_blocks = std::max(1u, std::min(r->masked_meshlets, 256u * 16u));
     g.deferred_blocks = fv.tiles_x * fv.tiles_y; // one workgroup per 64x64 tile
     g.shade_blocks_x = (r->width + 15u) / 16u;
     g.shade_blocks_y = (fv.row_hi - fv.row_lo + 15u) / 16u;
     g.slot_draw = 0;
     g.slot_cull = g.slot_draw + g.draw_blocks;
     g.slot_raster = g.slot_cull + g.cull_blocks * kCullSlots;
-    g.slot_deferred = g.slot_raster + g.raster_blocks * kRasterSlots;
+    g.slot_deferred = g.slot_raster + (g.raster_blocks + g.raster_mask_blocks) * kRasterSlots;
     g.slot_shade = g.slot_deferred + g.deferred_blocks;
     g.slot_total = g.slot_shade + g.shade_blocks_x * ((r->height + 15u) / 16u);
     return fv;
@@ -349,7 +351,8 @@ int fetch_counters(rdr_renderer* r, FrameCounters* out) {
     RDR_HIP(hipMemcpy(out, r->counters.ptr, sizeof(FrameCounters), hipMemcpyDeviceToHost));
     RDR_CHECK(out->deferred_overflow == 0 && out->setup_overflow == 0 && out->bin_overflow == 0,
               "frame: a tile-path list (deferred triangles, setup records or bins) overflowed; triangles were dropped");
-    RDR_CHECK(out->cmd_count <= r->commands.count && out->vis_count <= r->visible.count, "frame: a work list overflowed");
+    RDR_CHECK(out->cmd_count <= r->commands.count && (uint64_t)out->vis_count + out->vis_mask_count <= r->visible.count,
+              "frame: a work list overflowed");
     return 0;
 }
 
@@ -458,7 +461,7 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
     RDR_HIP(hipMemset(r->draw_lod.ptr, 0xFF, std::max<size_t>(s.draw_count, 1)));
 
     // meshlet instance -> draw, and work-list capacities
-    uint64_t cmd_cap = 0, vis_cap = 0, tri_total = 0;
+    uint64_t cmd_cap = 0, vis_cap = 0, tri_total = 0, masked_total = 0;
     {
         std::vector<uint32_t> inst(std::max<uint32_t>(s.meshlet_visibility_count, 1), 0u);
         for (uint32_t di = 0; di < s.draw_count; ++di) {
@@ -466,11 +469,13 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
             const rdr_mesh& m = s.meshes[d.mesh_index];
             const uint32_t n0 = m.lods[0].meshlet_count;
             for (uint32_t k = 0; k < n0; ++k) inst[d.meshlet_visibility_offset + k] = di;
+            if (d.alpha_mode == 1u) masked_total += n0;
             cmd_cap += (n0 + 63) / 64;
             vis_cap += n0;
             tri_total += (uint64_t)n0 * 124;
         }
         if (r->instance_draw.upload(inst.data(), inst.size())) return 1;
+        r->masked_meshlets = (uint32_t)masked_total;
     }
     if (r->commands.alloc(cmd_cap) || r->visible.alloc(vis_cap)) return 1;
     {
@@ -675,7 +680,7 @@ int rdr_get_stats(rdr_renderer* r, rdr_stats* out) {
             const uint32_t* p = &slots[g.slot_cull + b * kCullSlots];
             st.meshlets_tested += p[0]; st.meshlets_visible += p[1]; st.triangles_submitted += p[2];
         }
-        for (uint32_t b = 0; b < g.raster_blocks; ++b) {
+        for (uint32_t b = 0; b < g.raster_blocks + g.raster_mask_blocks; ++b) {
             const uint32_t* p = &slots[g.slot_raster + b * kRasterSlots];
             st.triangles_tested += p[0]; st.triangles_rasterised += p[1]; st.triangles_big += p[2];
             st.fragments += p[3]; st.vertices_transformed += p[4];

@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void k_draw_cull(SceneView sv, FrameView fv) {
 // ------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_meshlet_cull(SceneView sv, FrameView fv) {
     __shared__ uint32_t wave_count[16];
-    __shared__ uint32_t wg_base;
+    __shared__ uint32_t wave_masked[16];
+    __shared__ uint32_t wg_base[2];
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
     const rdr_ubo& u = fv.ubo;
@@ -120,13 +121,14 @@ __global__ __launch_bounds__(1024) void k_meshlet_cull(SceneView sv, FrameView f
     for (uint32_t c0 = blockIdx.x * 16u; c0 < cmd_count; c0 += gridDim.x * 16u) {
         const uint32_t ci = c0 + wave;
         bool accept = false;
-        uint32_t draw_id = 0, first = 0, instance_first = 0, tri_count = 0, count = 0;
+        uint32_t draw_id = 0, first = 0, instance_first = 0, tri_count = 0, count = 0, masked = 0;
         if (ci < cmd_count) {
             const CullCommand* cp = &fv.commands[__builtin_amdgcn_readfirstlane(ci)];
             draw_id = cp->draw_id; first = cp->meshlet_first; count = cp->count;
             instance_first = cp->instance_first;
             const float max_scale = cp->max_scale;
             const uint32_t model_index = sv.draws[draw_id].model_index;
+            masked = sv.draws[draw_id].alpha_mode == 1u ? 1u : 0u;
             float model[16];
             load_m4(sv.transforms + (size_t)model_index * 16, model);
             accept = lane < count;
@@ -150,18 +152,21 @@ __global__ __launch_bounds__(1024) void k_meshlet_cull(SceneView sv, FrameView f
         }
         const unsigned long long mask = __ballot(accept);
         const uint32_t n_acc = (uint32_t)__popcll(mask);
-        if (lane == 0) wave_count[wave] = n_acc;
+        if (lane == 0) { wave_count[wave] = n_acc; wave_masked[wave] = masked; }
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (threadIdx.x < 2) { // thread 0: opaque meshlets, thread 1: alpha-masked meshlets
             uint32_t total = 0;
-            for (int w = 0; w < 16; ++w) total += wave_count[w];
-            wg_base = total ? atomicAdd(&fv.counters->vis_count, total) : 0u;
+            for (int w = 0; w < 16; ++w) total += wave_masked[w] == threadIdx.x ? wave_count[w] : 0u;
+            uint32_t* head = threadIdx.x ? &fv.counters->vis_mask_count : &fv.counters->vis_count;
+            wg_base[threadIdx.x] = total ? atomicAdd(head, total) : 0u;
         }
         __syncthreads();
         if (accept) {
-            uint32_t slot = wg_base + ballot_rank(mask);
-            for (uint32_t w = 0; w < wave; ++w) slot += wave_count[w];
-            if (slot < fv.visible_capacity) {
+            uint32_t rank = wg_base[masked] + ballot_rank(mask);
+            for (uint32_t w = 0; w < wave; ++w) rank += wave_masked[w] == masked ? wave_count[w] : 0u;
+            // the opaque list grows from the front of the buffer, the masked list from its back
+            const uint32_t slot = masked ? fv.visible_capacity - 1u - rank : rank;
+            if (rank < fv.visible_capacity) {
                 VisibleMeshlet v;
                 v.draw_id = draw_id;
                 v.meshlet_index = first + lane;
@@ -324,11 +329,11 @@ RDR_DEV void edges_at(const TriSetup<I>& t, int px, int py, I& e01, I& e12, I& e
 }
 
 // Coverage + alpha + depth + atomic for one sample. Returns 1 when a fragment was produced.
-template <typename I>
+template <typename I, bool MASK>
 RDR_DEV uint32_t shade_sample(const SceneView& sv, const FrameView& fv, const TriSetup<I>& t, const AlphaTest& at,
                               int px, int py, I e01, I e12, I e20, uint32_t id) {
     if (((e01 + (I)t.bias01) | (e12 + (I)t.bias12) | (e20 + (I)t.bias20)) < 0) return 0;
-    if (at.enabled) {
+    if (MASK && at.enabled) {
         float alpha = 1.0f;
         if (at.has_tex) {
             float u, v, ux, vx, uy, vy;
@@ -350,7 +355,7 @@ RDR_DEV uint32_t shade_sample(const SceneView& sv, const FrameView& fv, const Tr
 }
 
 // One lane scans the whole bounding box.
-template <typename I>
+template <typename I, bool MASK>
 RDR_DEV uint32_t scan_lane(const SceneView& sv, const FrameView& fv, const TriSetup<I>& t, const AlphaTest& at, uint32_t id) {
     uint32_t frags = 0;
     I r01, r12, r20;
@@ -358,7 +363,7 @@ RDR_DEV uint32_t scan_lane(const SceneView& sv, const FrameView& fv, const TriSe
     for (int py = t.py0; py <= t.py1; ++py) {
         I e01 = r01, e12 = r12, e20 = r20;
         for (int px = t.px0; px <= t.px1; ++px) {
-            frags += shade_sample<I>(sv, fv, t, at, px, py, e01, e12, e20, id);
+            frags += shade_sample<I, MASK>(sv, fv, t, at, px, py, e01, e12, e20, id);
             e01 -= t.dy01 * 256; e12 -= t.dy12 * 256; e20 -= t.dy20 * 256;
         }
         r01 += t.dx01 * 256; r12 += t.dx12 * 256; r20 += t.dx20 * 256;
@@ -369,28 +374,37 @@ RDR_DEV uint32_t scan_lane(const SceneView& sv, const FrameView& fv, const TriSe
 // Per-wave LDS: the transformed vertices of one meshlet.
 struct MeshletLds {
     float cx[64], cy[64], cz[64], cw[64]; // clip space
+    float z[64];                          // z / w
     float sx[64], sy[64];                 // the mesh shader's y-up screen position
     int32_t X[64], Y[64];                 // snapped framebuffer position
     uint32_t clip[64];                    // vertex is outside the near plane / guard band
 };
 
+// MASK = false: meshlets of opaque draws (front of the visible list); MASK = true:
+// meshlets of alpha-tested draws (back of the list).  Two instantiations so that the
+// opaque one carries no uv / texture state in registers.
+template <bool MASK>
 __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
     __shared__ MeshletLds lds;
     const uint32_t lane = threadIdx.x;
     const rdr_ubo& u = fv.ubo;
-    const uint32_t vis_count = min(fv.counters->vis_count, fv.visible_capacity);
+    const uint32_t n_opaque = min(fv.counters->vis_count, fv.visible_capacity);
+    const uint32_t n_masked = min(fv.counters->vis_mask_count, fv.visible_capacity - n_opaque);
+    const uint32_t vis_count = MASK ? n_masked : n_opaque;
     const float half_w = (float)fv.width * 0.5f, half_h = (float)fv.height * 0.5f;
 
     uint32_t st_tested = 0, st_raster = 0, st_big = 0, st_frags = 0, st_verts = 0;
     for (uint32_t mi = blockIdx.x; mi < vis_count; mi += gridDim.x) {
-        const VisibleMeshlet vm = fv.visible[mi];
+        const VisibleMeshlet vm = fv.visible[MASK ? fv.visible_capacity - 1u - mi : mi];
         const rdr_mesh_draw d = sv.draws[vm.draw_id];
         const rdr_meshlet m = sv.meshlets[vm.meshlet_index];
         const uint32_t mesh_vertex_offset = sv.meshes[d.mesh_index].vertex_offset;
         float model[16];
         load_m4(sv.transforms + (size_t)d.model_index * 16, model);
-        const AlphaTest at = make_alpha_test(sv, d);
-        const bool cull_front = d.alpha_mode == 0u;
+        AlphaTest at;
+        at.enabled = false; at.has_tex = false;
+        if (MASK) at = make_alpha_test(sv, d);
+        const bool cull_front = !MASK;
 
         __syncthreads(); // previous meshlet's readers are done
         if (lane < m.vertex_count) {
@@ -399,6 +413,7 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
             const vec4 world = mul_m4(model, mk4(sv.pos_x[vi], sv.pos_y[vi], sv.pos_z[vi], 1.0f));
             const vec4 clip = mul_m4(u.view_proj, world);
             lds.cx[lane] = clip.x; lds.cy[lane] = clip.y; lds.cz[lane] = clip.z; lds.cw[lane] = clip.w;
+            lds.z[lane] = clip.z / clip.w;
             lds.sx[lane] = (clip.x / clip.w * 0.5f + 0.5f) * u.screen_width;
             lds.sy[lane] = (clip.y / clip.w * 0.5f + 0.5f) * u.screen_height;
             const bool nc = vert_needs_clip(clip.x, clip.y, clip.z, clip.w);
@@ -437,14 +452,14 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
                         defer = ex > kSmallExtent || ey > kSmallExtent;
                         if (!defer) {
                             SnapVert s0, s1, s2;
-                            s0.X = X0; s0.Y = Y0; s0.z = lds.cz[ia] / lds.cw[ia];
-                            s1.X = X1; s1.Y = Y1; s1.z = lds.cz[ib] / lds.cw[ib];
-                            s2.X = X2; s2.Y = Y2; s2.z = lds.cz[ic] / lds.cw[ic];
+                            s0.X = X0; s0.Y = Y0; s0.z = lds.z[ia];
+                            s1.X = X1; s1.Y = Y1; s1.z = lds.z[ib];
+                            s2.X = X2; s2.Y = Y2; s2.z = lds.z[ic];
                             s0.inv_w = s1.inv_w = s2.inv_w = 0.0f;
                             s0.u0 = s0.v0 = s0.u1 = s0.v1 = 0.0f;
                             s1.u0 = s1.v0 = s1.u1 = s1.v1 = 0.0f;
                             s2.u0 = s2.v0 = s2.u1 = s2.v1 = 0.0f;
-                            if (at.enabled && at.has_tex) { // the alpha test needs perspective-correct uv
+                            if (MASK && at.has_tex) { // the alpha test needs perspective-correct uv
                                 const uint32_t* mv = sv.meshlet_vertices + m.vertex_offset;
                                 const rdr_vertex* va = &sv.vertices[mv[ia] + mesh_vertex_offset];
                                 const rdr_vertex* vb = &sv.vertices[mv[ib] + mesh_vertex_offset];
@@ -458,7 +473,7 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
                             if (ts.valid) {
                                 const int npx = (ts.px1 - ts.px0 + 1) * (ts.py1 - ts.py0 + 1);
                                 defer = npx > kLaneMaxPixels;
-                                if (!defer) st_frags += scan_lane<int32_t>(sv, fv, ts, at, (vm.instance << 7) | ti);
+                                if (!defer) st_frags += scan_lane<int32_t, MASK>(sv, fv, ts, at, (vm.instance << 7) | ti);
                             }
                         }
                     }
@@ -502,7 +517,7 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
         const uint32_t a = wave_sum(st_tested), b = wave_sum(st_raster), c = wave_sum(st_big), f = wave_sum(st_frags);
         const uint32_t v = wave_sum(st_verts);
         if (lane == 0) {
-            uint32_t* slot = fv.stat_slots + fv.grid.slot_raster + blockIdx.x * kRasterSlots;
+            uint32_t* slot = fv.stat_slots + fv.grid.slot_raster + (blockIdx.x + (MASK ? fv.grid.raster_blocks : 0u)) * kRasterSlots;
             slot[0] = a; slot[1] = b; slot[2] = c; slot[3] = f; slot[4] = v;
         }
     }
@@ -899,7 +914,8 @@ int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t st
         // persistent grids: the work-list lengths live in device memory
         hipLaunchKernelGGL(k_meshlet_cull, dim3(fv.grid.cull_blocks), dim3(1024), 0, stream, sv, fv);
         if (ev) RDR_HIP(hipEventRecord(ev[3], stream));
-        hipLaunchKernelGGL(k_raster, dim3(fv.grid.raster_blocks), dim3(64), 0, stream, sv, fv);
+        hipLaunchKernelGGL(k_raster<false>, dim3(fv.grid.raster_blocks), dim3(64), 0, stream, sv, fv);
+        hipLaunchKernelGGL(k_raster<true>, dim3(fv.grid.raster_mask_blocks), dim3(64), 0, stream, sv, fv);
         if (ev) RDR_HIP(hipEventRecord(ev[4], stream));
         hipLaunchKernelGGL(k_tile_setup, dim3(256), dim3(256), 0, stream, sv, fv);
         hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, fv);

@@ -89,7 +89,8 @@ struct FrameCounters {
     uint32_t setup_overflow;
     uint32_t bin_total;       // tile-bin entries needed this frame
     uint32_t bin_overflow;
-    uint32_t _pad0[7];
+    uint32_t vis_mask_count;  // alpha-masked meshlets, stored from the back of `visible`
+    uint32_t _pad0[6];
     unsigned long long _pad1[16];
 };
 static_assert(sizeof(FrameCounters) == 192, "FrameCounters layout");
@@ -172,7 +173,7 @@ struct SceneView {
 
 // Launch geometry of one frame and where each kernel's workgroups put their statistics.
 struct GridPlan {
-    uint32_t draw_blocks, cull_blocks, raster_blocks, deferred_blocks, shade_blocks_x, shade_blocks_y;
+    uint32_t draw_blocks, cull_blocks, raster_blocks, raster_mask_blocks, deferred_blocks, shade_blocks_x, shade_blocks_y;
     uint32_t slot_draw, slot_cull, slot_raster, slot_deferred, slot_shade, slot_total;
 };
 constexpr uint32_t kCullSlots = 4, kRasterSlots = 8;
