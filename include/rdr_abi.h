@@ -233,7 +233,7 @@ enum {
     RDR_K_SHADOW = 4,
     RDR_K_BIG_RASTER = 5,
     RDR_K_SHADE = 6,
-    RDR_K_RESOLVE = 7
+    RDR_K_CLASSIFY = 7
 };
 
 typedef struct rdr_stats {

@@ -171,7 +171,7 @@ class Config(C.Structure):
 
 
 STAT_KERNELS = 8
-KERNEL_NAMES = ["clear", "draw_cull", "meshlet_cull", "raster", "shadow", "big_raster", "shade", "resolve"]
+KERNEL_NAMES = ["clear", "draw_cull", "meshlet_cull", "raster", "shadow", "big_raster", "shade", "classify"]
 
 
 class Stats(C.Structure):

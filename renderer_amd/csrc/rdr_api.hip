@@ -60,7 +60,7 @@ struct rdr_renderer {
     hipStream_t stream = nullptr;
     // time_kernels: a ring of per-frame event sets so that timing never forces a host sync
     static constexpr int kRing = 64;
-    static constexpr int kEvents = 9;
+    static constexpr int kEvents = 10;
     std::vector<hipEvent_t> ring; // kRing * kEvents
     bool slot_geometry[kRing]{}, slot_shade[kRing]{};
     uint64_t frames_started = 0; // frames since the last rdr_get_stats
@@ -80,6 +80,7 @@ struct rdr_renderer {
     DeviceBuffer<uint32_t> resolve_out;
     DeviceBuffer<float> srgb_lut;
     DeviceBuffer<uint8_t> shadow;
+    DeviceBuffer<uint32_t> pixel_list;
     DeviceBuffer<uint32_t> stat_slots;
 
     // scene resources
@@ -317,6 +318,7 @@ FrameView make_frame_view(rdr_renderer* r) {
     fv.deferred_capacity = (uint32_t)r->deferred.count;
     fv.collect_stats = r->cfg.collect_stats;
     fv.shadow = r->shadow.ptr;
+    fv.pixel_list = r->pixel_list.ptr;
     fv.lds_stack_limit = r->lds_stack_limit;
     fv.setup = r->setup.ptr;
     fv.setup_mask = r->setup_mask.ptr;
@@ -342,7 +344,7 @@ FrameView make_frame_view(rdr_renderer* r) {
     g.slot_raster = g.slot_cull + g.cull_blocks * kCullSlots;
     g.slot_deferred = g.slot_raster + (g.raster_blocks + g.raster_mask_blocks) * kRasterSlots;
     g.slot_shade = g.slot_deferred + g.deferred_blocks;
-    g.slot_total = g.slot_shade + g.shade_blocks_x * ((r->height + 15u) / 16u);
+    g.slot_total = g.slot_shade;
     return fv;
 }
 
@@ -389,7 +391,8 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
         for (auto& e : r->ring) RDR_HIP(hipEventCreate(&e));
     }
     const size_t npx = (size_t)width * height;
-    if (r->vis.alloc(npx) || r->color.alloc(npx * 4) || r->counters.alloc(1) || r->shadow.alloc(npx)) return 1;
+    if (r->vis.alloc(npx) || r->color.alloc(npx * 4) || r->counters.alloc(1) || r->shadow.alloc(npx) ||
+        r->pixel_list.alloc(npx)) return 1;
     {
         const size_t n_tiles = (size_t)((width + 63) / 64) * ((height + 63) / 64);
         if (r->tile_count.alloc(n_tiles) || r->tile_offset.alloc(n_tiles) || r->tile_cursor.alloc(n_tiles)) return 1;
@@ -686,11 +689,10 @@ int rdr_get_stats(rdr_renderer* r, rdr_stats* out) {
             st.fragments += p[3]; st.vertices_transformed += p[4];
         }
         for (uint32_t b = 0; b < g.deferred_blocks; ++b) st.fragments += slots[g.slot_deferred + b];
-        if (r->shaded)
-            for (uint32_t b = 0; b < g.shade_blocks_x * g.shade_blocks_y; ++b) st.pixels_covered += slots[g.slot_shade + b];
+        if (r->shaded) st.pixels_covered = fc.pixel_count;
     }
     if (r->cfg.time_kernels && r->frames_started) {
-        // events 0..5 bracket clear, draw cull, meshlet cull, raster, deferred; 6..8 bracket shadow and shading.
+        // events 0..5 bracket clear, draw cull, meshlet cull, raster, deferred; 6..9 bracket classification, shadow and shading.
         // Mean over the frames still in the ring (the stream was synchronised above).
         const int map[5] = {RDR_K_CLEAR, RDR_K_DRAW_CULL, RDR_K_MESHLET_CULL, RDR_K_RASTER, RDR_K_BIG_RASTER};
         const int n = (int)std::min<uint64_t>(r->frames_started, rdr_renderer::kRing);
@@ -708,9 +710,10 @@ int rdr_get_stats(rdr_renderer* r, rdr_stats* out) {
                 }
             }
             if (r->slot_shade[f]) {
-                float ms0 = 0.0f, ms1 = 0.0f;
-                if (hipEventElapsedTime(&ms0, ev[6], ev[7]) == hipSuccess && hipEventElapsedTime(&ms1, ev[7], ev[8]) == hipSuccess) {
-                    sum[RDR_K_SHADOW] += ms0; sum[RDR_K_SHADE] += ms1; n_shade++;
+                float ms0 = 0.0f, ms1 = 0.0f, ms2 = 0.0f;
+                if (hipEventElapsedTime(&ms0, ev[6], ev[7]) == hipSuccess && hipEventElapsedTime(&ms1, ev[7], ev[8]) == hipSuccess &&
+                    hipEventElapsedTime(&ms2, ev[8], ev[9]) == hipSuccess) {
+                    sum[RDR_K_CLASSIFY] += ms0; sum[RDR_K_SHADOW] += ms1; sum[RDR_K_SHADE] += ms2; n_shade++;
                 }
             }
             r->slot_geometry[f] = r->slot_shade[f] = false;
@@ -720,6 +723,7 @@ int rdr_get_stats(rdr_renderer* r, rdr_stats* out) {
         if (n_shade) {
             st.kernel_ms[RDR_K_SHADE] = (float)(sum[RDR_K_SHADE] / n_shade);
             st.kernel_ms[RDR_K_SHADOW] = (float)(sum[RDR_K_SHADOW] / n_shade);
+            st.kernel_ms[RDR_K_CLASSIFY] = (float)(sum[RDR_K_CLASSIFY] / n_shade);
         }
         st.frames_timed = (uint64_t)n_geo;
         r->frames_started = 0;

@@ -84,13 +84,14 @@ struct FrameCounters {
     uint32_t vis_count;
     uint32_t deferred_count;
     uint32_t deferred_overflow;
-    uint32_t shadow_overflow; // pixels k_shadow left to k_shadow_deep
+    uint32_t pixel_count;     // covered pixels in the shaded rows (length of pixel_list)
+    uint32_t shadow_overflow; // pixels k_shadow left to k_shadow_deep (must follow pixel_count)
     uint32_t setup_count;     // SetupTri records written this frame
     uint32_t setup_overflow;
     uint32_t bin_total;       // tile-bin entries needed this frame
     uint32_t bin_overflow;
     uint32_t vis_mask_count;  // alpha-masked meshlets, stored from the back of `visible`
-    uint32_t _pad0[6];
+    uint32_t _pad0[5];
     unsigned long long _pad1[16];
 };
 static_assert(sizeof(FrameCounters) == 192, "FrameCounters layout");
@@ -191,7 +192,8 @@ struct FrameView {
     uint32_t row_lo, row_hi;
     uint32_t command_capacity, visible_capacity, deferred_capacity;
     uint32_t collect_stats;
-    uint8_t* shadow; // one byte per pixel: 1 = the sun ray is blocked
+    uint32_t* pixel_list; // indices of the covered pixels in the shaded rows (k_classify)
+    uint8_t* shadow;      // one byte per pixel_list entry: 1 = the sun ray is blocked
     SetupTri* setup;
     SetupMask* setup_mask;
     uint32_t* tile_count;  // per tile: triangles binned

@@ -534,107 +534,136 @@ RDR_DEV void decode_key(const SceneView& sv, unsigned long long key, uint32_t& d
     meshlet = L.meshlet_offset + (instance - d.meshlet_visibility_offset);
 }
 
-// 16x16 pixels per workgroup, each wave an 8x8 block.
-RDR_DEV void pixel_of_thread(const FrameView& fv, uint32_t& ix, uint32_t& iy) {
+// Pass 0: classification.  A workgroup owns a 64x64-pixel region as sixteen 16x16 blocks, each
+// wave an 8x8 sub-block.  Pixels with no geometry get the shading pass's clear colour here;
+// covered pixels are appended to a compact pixel list, which the two passes below run over
+// with full waves.  One atomic per workgroup reserves the region's span of the list (same-
+// address atomics serialise, so they are kept to a few thousand per frame); inside the span
+// the order is block-, wave-, lane-major, so 64 consecutive entries stay spatially close.
+constexpr uint32_t kClassifyRegion = 64;
+
+__global__ __launch_bounds__(256) void k_classify(FrameView fv) {
+    __shared__ uint32_t wave_count[16 * 4];
+    __shared__ uint32_t wg_base;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    ix = blockIdx.x * 16 + (wave & 1u) * 8 + (lane & 7u);
-    iy = fv.row_lo + blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const uint32_t x0 = blockIdx.x * kClassifyRegion + (wave & 1u) * 8 + (lane & 7u);
+    const uint32_t y0 = fv.row_lo + blockIdx.y * kClassifyRegion + (wave >> 1) * 8 + (lane >> 3);
+    uint32_t covered_bits = 0;
+    uint32_t* color = reinterpret_cast<uint32_t*>(fv.color);
+#pragma unroll
+    for (uint32_t b = 0; b < 16; ++b) {
+        const uint32_t ix = x0 + (b & 3u) * 16, iy = y0 + (b >> 2) * 16;
+        bool covered = false;
+        if (ix < fv.width && iy < fv.row_hi) {
+            const uint32_t pi = iy * fv.width + ix;
+            covered = fv.vis[pi] != RDR_VIS_CLEAR;
+            if (!covered) color[pi] = 0u; // the shading pass clears its target to (0,0,0,0)
+        }
+        const unsigned long long m = __ballot(covered);
+        if (lane == 0) wave_count[b * 4 + wave] = (uint32_t)__popcll(m);
+        covered_bits |= covered ? (1u << b) : 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) { // exclusive prefix sum of the 64 (block, wave) counts
+        const uint32_t c = wave_count[threadIdx.x];
+        const uint32_t inc = wave_scan_inclusive(c, lane);
+        wave_count[threadIdx.x] = inc - c;
+        if (threadIdx.x == 63) wg_base = inc ? atomicAdd(&fv.counters->pixel_count, inc) : 0u;
+    }
+    __syncthreads();
+    const uint32_t base = wg_base;
+#pragma unroll
+    for (uint32_t b = 0; b < 16; ++b) {
+        const bool covered = (covered_bits >> b) & 1u;
+        const unsigned long long m = __ballot(covered);
+        if (covered) {
+            const uint32_t ix = x0 + (b & 3u) * 16, iy = y0 + (b >> 2) * 16;
+            fv.pixel_list[base + wave_count[b * 4 + wave] + ballot_rank(m)] = iy * fv.width + ix;
+        }
+    }
+}
+
+struct ListedPixel {
+    uint32_t pi, draw_id, meshlet, tri;
+    float uvx, uvy;
+};
+
+RDR_DEV ListedPixel listed_pixel(const SceneView& sv, const FrameView& fv, uint32_t entry) {
+    ListedPixel p;
+    p.pi = fv.pixel_list[entry];
+    decode_key(sv, fv.vis[p.pi], p.draw_id, p.meshlet, p.tri);
+    const uint32_t iy = p.pi / fv.width, ix = p.pi - iy * fv.width;
+    p.uvx = ((float)ix + 0.5f) / (float)fv.width;
+    p.uvy = 1.0f - ((float)iy + 0.5f) / (float)fv.height;
+    return p;
 }
 
 // Pass 1: the sun shadow ray of every covered pixel (shading.frag.glsl:421-425), kept
 // apart from the material evaluation so that the pointer-chasing traversal runs at
-// high occupancy with its stack in LDS.
+// high occupancy with its stack in LDS.  The result is stored per list entry.
 __global__ __launch_bounds__(256) void k_shadow(SceneView sv, FrameView fv) {
     __shared__ uint32_t stack_mem[kLdsStack * 256];
-    uint32_t ix, iy;
-    pixel_of_thread(fv, ix, iy);
-    if (ix >= fv.width || iy >= fv.row_hi) return;
-    const size_t pi = (size_t)iy * fv.width + ix;
-    const unsigned long long key = fv.vis[pi];
-    uint8_t hit = 0;
-    if (key != RDR_VIS_CLEAR) {
-        uint32_t draw_id, meshlet, tri;
-        decode_key(sv, key, draw_id, meshlet, tri);
-        const float uvx = ((float)ix + 0.5f) / (float)fv.width;
-        const float uvy = 1.0f - ((float)iy + 0.5f) / (float)fv.height;
-        const vec3 w_pos = pixel_world_position(sv, fv.ubo, draw_id, meshlet, tri, uvx, uvy);
-        const rdr_ubo& u = fv.ubo;
-        const vec3 L = normalize3(mk3(u.sun_direction[0], u.sun_direction[1], u.sun_direction[2]));
-        LdsStack st;
-        st.base = stack_mem + threadIdx.x;
-        st.limit = (int)fv.lds_stack_limit;
-        const bool h = shadow_any_hit(sv, draw_id, w_pos, L, 1e-2f, 1000.0f, st);
-        hit = h ? 1 : 0;
-        if (!h && st.overflow) { // a miss that dropped stack entries proves nothing: leave it to k_shadow_deep
-            hit = 2;
-            atomicAdd(&fv.counters->shadow_overflow, 1u);
-        }
+    const uint32_t entry = blockIdx.x * 256u + threadIdx.x;
+    if (entry >= fv.counters->pixel_count) return;
+    const ListedPixel p = listed_pixel(sv, fv, entry);
+    const vec3 w_pos = pixel_world_position(sv, fv.ubo, p.draw_id, p.meshlet, p.tri, p.uvx, p.uvy);
+    const rdr_ubo& u = fv.ubo;
+    const vec3 L = normalize3(mk3(u.sun_direction[0], u.sun_direction[1], u.sun_direction[2]));
+    LdsStack st;
+    st.base = stack_mem + threadIdx.x;
+    st.limit = (int)fv.lds_stack_limit;
+    const bool h = shadow_any_hit(sv, p.draw_id, w_pos, L, 1e-2f, 1000.0f, st);
+    uint8_t hit = h ? 1 : 0;
+    if (!h && st.overflow) { // a miss that dropped stack entries proves nothing: leave it to k_shadow_deep
+        hit = 2;
+        atomicAdd(&fv.counters->shadow_overflow, 1u);
     }
-    fv.shadow[pi] = hit;
+    fv.shadow[entry] = hit;
 }
 
 // Pass 1b: pixels whose traversal overflowed the LDS stack, traced again with the deep
 // scratch-backed stack.  Exits at once when there are none (the normal case).
 __global__ __launch_bounds__(256) void k_shadow_deep(SceneView sv, FrameView fv) {
     if (fv.counters->shadow_overflow == 0u) return;
-    const size_t first = (size_t)fv.row_lo * fv.width, last = (size_t)fv.row_hi * fv.width;
+    const uint32_t count = fv.counters->pixel_count;
     const rdr_ubo& u = fv.ubo;
-    for (size_t pi = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x; pi < last; pi += (size_t)gridDim.x * blockDim.x) {
-        if (fv.shadow[pi] != 2) continue;
-        const uint32_t ix = (uint32_t)(pi % fv.width), iy = (uint32_t)(pi / fv.width);
-        uint32_t draw_id, meshlet, tri;
-        decode_key(sv, fv.vis[pi], draw_id, meshlet, tri);
-        const float uvx = ((float)ix + 0.5f) / (float)fv.width;
-        const float uvy = 1.0f - ((float)iy + 0.5f) / (float)fv.height;
-        const vec3 w_pos = pixel_world_position(sv, u, draw_id, meshlet, tri, uvx, uvy);
+    for (uint32_t entry = blockIdx.x * blockDim.x + threadIdx.x; entry < count; entry += gridDim.x * blockDim.x) {
+        if (fv.shadow[entry] != 2) continue;
+        const ListedPixel p = listed_pixel(sv, fv, entry);
+        const vec3 w_pos = pixel_world_position(sv, u, p.draw_id, p.meshlet, p.tri, p.uvx, p.uvy);
         const vec3 L = normalize3(mk3(u.sun_direction[0], u.sun_direction[1], u.sun_direction[2]));
         DeepStack st;
-        fv.shadow[pi] = shadow_any_hit(sv, draw_id, w_pos, L, 1e-2f, 1000.0f, st) ? 1 : 0;
+        fv.shadow[entry] = shadow_any_hit(sv, p.draw_id, w_pos, L, 1e-2f, 1000.0f, st) ? 1 : 0;
     }
 }
 
-// Pass 2: material evaluation, lighting, sRGB store.
+// Pass 2: material evaluation, lighting, sRGB store of every covered pixel.
 __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv) {
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t ix, iy;
-    pixel_of_thread(fv, ix, iy);
-    bool covered = false;
-    if (ix < fv.width && iy < fv.row_hi) {
-        const size_t pi = (size_t)iy * fv.width + ix;
-        const unsigned long long key = fv.vis[pi];
-        uint32_t out = 0u; // the shading pass clears its target to (0,0,0,0)
-        if (key != RDR_VIS_CLEAR) {
-            covered = true;
-            uint32_t draw_id, meshlet, tri;
-            decode_key(sv, key, draw_id, meshlet, tri);
-            const float uvx = ((float)ix + 0.5f) / (float)fv.width;
-            const float uvy = 1.0f - ((float)iy + 0.5f) / (float)fv.height;
-            const vec3 c = shade_pixel(sv, fv.ubo, draw_id, meshlet, tri, uvx, uvy, fv.shadow[pi] != 0);
-            out = srgb_encode(c.x) | (srgb_encode(c.y) << 8) | (srgb_encode(c.z) << 16) | (255u << 24);
-        }
-        reinterpret_cast<uint32_t*>(fv.color)[pi] = out;
-    }
-    if (fv.collect_stats) {
-        __shared__ uint32_t wg_cov[4];
-        const unsigned long long m = __ballot(covered);
-        if (lane == 0) wg_cov[threadIdx.x >> 6] = (uint32_t)__popcll(m);
-        __syncthreads();
-        if (threadIdx.x == 0)
-            fv.stat_slots[fv.grid.slot_shade + blockIdx.y * gridDim.x + blockIdx.x] = wg_cov[0] + wg_cov[1] + wg_cov[2] + wg_cov[3];
-    }
+    const uint32_t entry = blockIdx.x * 256u + threadIdx.x;
+    if (entry >= fv.counters->pixel_count) return;
+    const ListedPixel p = listed_pixel(sv, fv, entry);
+    const vec3 c = shade_pixel(sv, fv.ubo, p.draw_id, p.meshlet, p.tri, p.uvx, p.uvy, fv.shadow[entry] != 0);
+    reinterpret_cast<uint32_t*>(fv.color)[p.pi] =
+        srgb_encode(c.x) | (srgb_encode(c.y) << 8) | (srgb_encode(c.z) << 16) | (255u << 24);
 }
 
 } // namespace
 
 int rdr_launch_shade(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev) {
     if (fv.row_hi <= fv.row_lo) return 0;
-    const dim3 grid(fv.grid.shade_blocks_x, fv.grid.shade_blocks_y);
+    const dim3 tiles((fv.width + kClassifyRegion - 1u) / kClassifyRegion, (fv.row_hi - fv.row_lo + kClassifyRegion - 1u) / kClassifyRegion);
+    // the list passes are launched for the worst case (every pixel covered); workgroups
+    // beyond the list's length exit on their first instruction
+    const uint32_t list_blocks = (uint32_t)(((size_t)(fv.row_hi - fv.row_lo) * fv.width + 255u) / 256u);
     if (ev) RDR_HIP(hipEventRecord(ev[6], stream));
-    hipLaunchKernelGGL(k_shadow, grid, dim3(256), 0, stream, sv, fv);
-    hipLaunchKernelGGL(k_shadow_deep, dim3(512), dim3(256), 0, stream, sv, fv);
+    RDR_HIP(hipMemsetAsync(&fv.counters->pixel_count, 0, 2 * sizeof(uint32_t), stream)); // pixel_count, shadow_overflow
+    hipLaunchKernelGGL(k_classify, tiles, dim3(256), 0, stream, fv);
     if (ev) RDR_HIP(hipEventRecord(ev[7], stream));
-    hipLaunchKernelGGL(k_shade, grid, dim3(256), 0, stream, sv, fv);
+    hipLaunchKernelGGL(k_shadow, dim3(list_blocks), dim3(256), 0, stream, sv, fv);
+    hipLaunchKernelGGL(k_shadow_deep, dim3(512), dim3(256), 0, stream, sv, fv);
     if (ev) RDR_HIP(hipEventRecord(ev[8], stream));
+    hipLaunchKernelGGL(k_shade, dim3(list_blocks), dim3(256), 0, stream, sv, fv);
+    if (ev) RDR_HIP(hipEventRecord(ev[9], stream));
     RDR_HIP(hipGetLastError());
     return 0;
 }
