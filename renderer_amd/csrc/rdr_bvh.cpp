@@ -227,8 +227,8 @@ uint32_t emit_wide(const std::vector<BvhNode>& nodes, uint32_t node, std::vector
     for (int i = 0; i < kBvhWidth; ++i) {
         w.child[i] = codes[i];
         for (int k = 0; k < 3; ++k) {
-            w.box[i][k] = i < n ? float_to_half_dir(nodes[slots[i]].lo[k], false) : (uint16_t)0;
-            w.box[i][3 + k] = i < n ? float_to_half_dir(nodes[slots[i]].hi[k], true) : (uint16_t)0;
+            w.box[k][i][0] = i < n ? float_to_half_dir(nodes[slots[i]].lo[k], false) : (uint16_t)0;
+            w.box[k][i][1] = i < n ? float_to_half_dir(nodes[slots[i]].hi[k], true) : (uint16_t)0;
         }
     }
     return self;
@@ -243,8 +243,8 @@ void flatten(const std::vector<BvhNode>& nodes, std::vector<BvhWide>& out) {
     if (root.count) {
         w.child[0] = leaf_code(root);
         for (int k = 0; k < 3; ++k) {
-            w.box[0][k] = float_to_half_dir(root.lo[k], false);
-            w.box[0][3 + k] = float_to_half_dir(root.hi[k], true);
+            w.box[k][0][0] = float_to_half_dir(root.lo[k], false);
+            w.box[k][0][1] = float_to_half_dir(root.hi[k], true);
         }
     }
     out.push_back(w);

@@ -122,13 +122,14 @@ struct BvhNode {
 static_assert(sizeof(BvhNode) == 32, "BvhNode layout");
 
 // Traversal-side node: kBvhWidth children, each a code and a box of 6 halfs
-// (lo.xyz hi.xyz, rounded outward so the box only grows).  A child code is
+// (rounded outward so the box only grows), stored per axis as (min, max) pairs so
+// that a node is four aligned 16-byte loads: codes, x pairs, y pairs, z pairs.  A child code is
 // kBvhNone, a leaf (bit 31 | count << 24 | first item) or the index of the child's
 // own node.  Wide nodes keep the dependent-load chain of a traversal short.
 constexpr int kBvhWidth = 4;
 struct BvhWide {
     uint32_t child[kBvhWidth];
-    uint16_t box[kBvhWidth][6];
+    uint16_t box[3][kBvhWidth][2]; // [axis][child][min, max]
 };
 static_assert(sizeof(BvhWide) == kBvhWidth * 16, "BvhWide layout");
 constexpr uint32_t kBvhNone = 0xFFFFFFFFu;

@@ -17,21 +17,37 @@ constexpr float kPi = 3.1415926535897932384626433832795f;
 constexpr float kMinRoughness = 0.04f;
 
 // ---- shadow ray -------------------------------------------------------------------
-// Conservative ray / box slab test.  Only "never miss a box the ray touches" matters
-// for the result, so this uses the fast reciprocal and one widening of the final
-// interval (4e-6 relative, far above the accumulated rounding of ~3e-7).  NaNs
-// from 0 * inf fall out of min/max and never reject.
-RDR_DEV bool ray_box(float lx, float ly, float lz, float hx, float hy, float hz, vec3 o, vec3 inv_d, float tmin, float tmax) {
-    const float ax = (lx - o.x) * inv_d.x, bx = (hx - o.x) * inv_d.x;
-    const float ay = (ly - o.y) * inv_d.y, by = (hy - o.y) * inv_d.y;
-    const float az = (lz - o.z) * inv_d.z, bz = (hz - o.z) * inv_d.z;
-    const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
-    const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
-    return fmaf(-4e-6f, fabsf(t_in), t_in) <= fmaf(4e-6f, fabsf(t_out), t_out);
+// Conservative ray / box slab test on one child of a wide node.  `w` holds one axis of
+// the box as an fp16 pair (low half = box minimum, high half = box maximum).  Only "never
+// miss a box the ray touches" matters for the result, so the planes are evaluated as
+// t = plane * (1/d) + c with c = -o/d precomputed per ray: one mixed-precision FMA per
+// plane, with the half -> float conversion folded into it.  The rounding of c, of the fast
+// reciprocal and of the FMA is covered by a per-axis margin folded into the two constants
+// (c_near = c - m, c_far = c + m).  The pairs are rotated by the ray's direction sign so
+// that the low half is always the entry plane.  NaNs (0 * inf, inf - inf) fall out of
+// min/max and never reject.
+struct SlabRay {
+    vec3 inv_d;  // 1 / d
+    vec3 c_near; // -o / d - margin
+    vec3 c_far;  // -o / d + margin
+    uint32_t rx, ry, rz; // 16 where d < 0 on that axis, else 0: rotation that puts the entry plane low
+};
+
+RDR_DEV float half_of(uint32_t w, bool hi) {
+    return (float)__builtin_bit_cast(_Float16, (uint16_t)(hi ? (w >> 16) : (w & 0xFFFFu)));
 }
 
-RDR_DEV float half_lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xFFFFu)); }
-RDR_DEV float half_hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
+RDR_DEV bool ray_box(uint32_t wx, uint32_t wy, uint32_t wz, const SlabRay& r, float tmin, float tmax) {
+    wx = __builtin_amdgcn_alignbit(wx, wx, r.rx);
+    wy = __builtin_amdgcn_alignbit(wy, wy, r.ry);
+    wz = __builtin_amdgcn_alignbit(wz, wz, r.rz);
+    const float nx = fmaf(half_of(wx, false), r.inv_d.x, r.c_near.x), fx = fmaf(half_of(wx, true), r.inv_d.x, r.c_far.x);
+    const float ny = fmaf(half_of(wy, false), r.inv_d.y, r.c_near.y), fy = fmaf(half_of(wy, true), r.inv_d.y, r.c_far.y);
+    const float nz = fmaf(half_of(wz, false), r.inv_d.z, r.c_near.z), fz = fmaf(half_of(wz, true), r.inv_d.z, r.c_far.z);
+    const float t_in = fmaxf(fmaxf(fmaxf(nx, ny), nz), tmin);
+    const float t_out = fminf(fminf(fminf(fx, fy), fz), tmax);
+    return t_in <= t_out;
+}
 
 // Moeller-Trumbore without the division, two-sided, open interval (tmin, tmax): with
 // a = |det| and the numerators multiplied by sign(det), the ray hits when
@@ -84,105 +100,107 @@ struct DeepStack {
 };
 
 struct Ray {
-    vec3 o, d, inv_d;
+    vec3 o, d;
+    SlabRay slab;
 };
 
-RDR_DEV Ray make_ray(vec3 o, vec3 d) {
+// Margin per axis: |c| * 2^-24 (rounding of c) plus (2^-23 + 2^-24) * |t| for the
+// reciprocal and the FMA with |t| <= tmax where it can matter; (|c| + tmax) * 2^-21
+// covers both four times over.
+RDR_DEV Ray make_ray(vec3 o, vec3 d, float tmax) {
     Ray r;
     r.o = o; r.d = d;
-    r.inv_d = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    const vec3 inv = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    const vec3 c = mk3(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+    const float k = 4.76837158203125e-7f; // 2^-21
+    const vec3 m = mk3((fabsf(c.x) + tmax) * k, (fabsf(c.y) + tmax) * k, (fabsf(c.z) + tmax) * k);
+    r.slab.inv_d = inv;
+    r.slab.c_near = c - m;
+    r.slab.c_far = c + m;
+    r.slab.rx = d.x < 0.0f ? 16u : 0u;
+    r.slab.ry = d.y < 0.0f ? 16u : 0u;
+    r.slab.rz = d.z < 0.0f ? 16u : 0u;
     return r;
 }
 
 // The ray in an instance's object space: origin and (unnormalised) direction through
 // the inverse model matrix, parameter t unchanged.
-RDR_DEV Ray object_ray(const GpuInstance& inst, vec3 o, vec3 d) {
+RDR_DEV Ray object_ray(const GpuInstance& inst, vec3 o, vec3 d, float tmax) {
     const float* iv = inst.inv;
     const vec3 oo = mk3(((iv[0] * o.x + iv[1] * o.y) + iv[2] * o.z) + iv[3], ((iv[4] * o.x + iv[5] * o.y) + iv[6] * o.z) + iv[7],
                         ((iv[8] * o.x + iv[9] * o.y) + iv[10] * o.z) + iv[11]);
     const vec3 od = mk3((iv[0] * d.x + iv[1] * d.y) + iv[2] * d.z, (iv[4] * d.x + iv[5] * d.y) + iv[6] * d.z,
                         (iv[8] * d.x + iv[9] * d.y) + iv[10] * d.z);
-    return make_ray(oo, od);
+    return make_ray(oo, od, tmax);
 }
 
-// Is anything between the surface point and the sun?  One loop walks both levels:
-// `cur` is the child code being processed, the stack holds the ones still to do, and
-// `floor` is the stack height at which the current instance's BLAS is exhausted.
-// The result is a plain "any triangle hit", so the visiting order is free: the
-// pixel's own instance, by far the likeliest occluder, goes first and is skipped
-// when the top level meets it again.
+// Is anything between the surface point and the sun?  One loop walks both levels: `cur` is
+// the child code being processed, the stack holds the ones still to do, and `floor` is the
+// stack height at which the current instance's BLAS is exhausted (-1 while in the top
+// level).  The result is a plain "any triangle hit", so the visiting order is free: the
+// pixel's own instance, by far the likeliest occluder, goes first (with the top level's
+// root waiting at the bottom of the stack) and is skipped when the top level meets it
+// again.  Every iteration handles one node and, if that left nothing to continue with,
+// pops the next; state changes are in place so that the loop has one back edge.
 template <typename Stack>
 RDR_DEV bool shadow_any_hit(const SceneView& sv, uint32_t own_instance, vec3 o, vec3 d, float tmin, float tmax, Stack& st) {
     st.sp = 0;
     st.overflow = false;
-    const Ray world = make_ray(o, d);
-    Ray ray = object_ray(sv.instances[own_instance], o, d);
+    st.push(0u); // node 0 of a tree holds the children of its root
+    int floor = 1;
+    Ray ray = object_ray(sv.instances[own_instance], o, d, tmax);
     uint32_t node_base = sv.instances[own_instance].blas_root, tri_base = sv.instances[own_instance].tri_base;
-    uint32_t cur = 0u; // node 0 of a tree holds the children of its root
-    bool in_blas = true, tlas_started = false;
-    int floor = 0;
+    uint32_t cur = 0u;
+    bool hit = false;
     for (;;) {
-        if (cur == kBvhNone) {
-            if (in_blas && st.sp == floor) { // this instance is done: back to the world ray
-                in_blas = false;
-                ray = world;
-                node_base = sv.tlas_base;
-                floor = 0;
-                if (!tlas_started) {
-                    tlas_started = true;
-                    cur = 0u;
-                    continue;
-                }
-            }
-            if (st.sp == 0) return false;
-            cur = st.pop();
-        }
         if (!(cur & kBvhLeaf)) {
             // one wide node: all its loads are in flight together
             const uint4* q = reinterpret_cast<const uint4*>(sv.bvh + (node_base + cur));
-            uint32_t w[kBvhWidth * 4];
-#pragma unroll
-            for (int i = 0; i < kBvhWidth; ++i) {
-                const uint4 v = q[i];
-                w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
-            }
+            const uint4 codes = q[0], bx = q[1], by = q[2], bz = q[3];
+            const uint32_t code[4] = {codes.x, codes.y, codes.z, codes.w};
+            const uint32_t wx[4] = {bx.x, bx.y, bx.z, bx.w}, wy[4] = {by.x, by.y, by.z, by.w}, wz[4] = {bz.x, bz.y, bz.z, bz.w};
             cur = kBvhNone;
 #pragma unroll
             for (int i = 0; i < kBvhWidth; ++i) {
-                const uint32_t code = w[i];
-                const uint32_t* bx = &w[kBvhWidth + 3 * i];
-                const bool h = code != kBvhNone && ray_box(half_lo(bx[0]), half_hi(bx[0]), half_lo(bx[1]), half_hi(bx[1]), half_lo(bx[2]),
-                                                           half_hi(bx[2]), ray.o, ray.inv_d, tmin, tmax);
+                const bool h = (code[i] != kBvhNone) & ray_box(wx[i], wy[i], wz[i], ray.slab, tmin, tmax);
                 if (h) {
                     if (cur != kBvhNone) st.push(cur);
-                    cur = code;
+                    cur = code[i];
                 }
             }
-            continue;
-        }
-        const uint32_t count = (cur >> 24) & 127u, first = cur & 0xFFFFFFu;
-        if (in_blas) {
-            const float* tp = sv.blas_tris + (size_t)(tri_base + first) * 9;
-            for (uint32_t i = 0; i < count; ++i, tp += 9)
-                if (ray_triangle(ray.o, ray.d, mk3(tp[0], tp[1], tp[2]), mk3(tp[3], tp[4], tp[5]), mk3(tp[6], tp[7], tp[8]), tmin, tmax))
-                    return true;
+        } else if (cur != kBvhNone) {
+            const uint32_t count = (cur >> 24) & 127u, first = cur & 0xFFFFFFu;
             cur = kBvhNone;
-            continue;
+            if (floor >= 0) {
+                const float* tp = sv.blas_tris + (size_t)(tri_base + first) * 9;
+                for (uint32_t i = 0; i < count; ++i, tp += 9)
+                    hit |= ray_triangle(ray.o, ray.d, mk3(tp[0], tp[1], tp[2]), mk3(tp[3], tp[4], tp[5]), mk3(tp[6], tp[7], tp[8]), tmin, tmax);
+            } else {
+                // top-level leaf: take its first instance now, leave the others on the stack
+                const uint32_t instance = sv.tlas_items[first];
+                if (count > 1u) st.push(kBvhLeaf | ((count - 1u) << 24) | (first + 1u));
+                if (instance != own_instance) {
+                    const GpuInstance& inst = sv.instances[instance];
+                    ray = object_ray(inst, o, d, tmax);
+                    node_base = inst.blas_root;
+                    tri_base = inst.tri_base;
+                    floor = st.sp;
+                    cur = 0u;
+                }
+            }
         }
-        // top-level leaf: take its first instance now, leave the others on the stack
-        const uint32_t instance = sv.tlas_items[first];
-        if (count > 1u) st.push(kBvhLeaf | ((count - 1u) << 24) | (first + 1u));
-        cur = kBvhNone;
-        if (instance != own_instance) {
-            const GpuInstance& inst = sv.instances[instance];
-            ray = object_ray(inst, o, d);
-            node_base = inst.blas_root;
-            tri_base = inst.tri_base;
-            in_blas = true;
-            floor = st.sp;
-            cur = 0u;
+        if (hit) break;
+        if (cur == kBvhNone) {
+            if (st.sp == floor) { // this instance is done: back to the world ray
+                floor = -1;
+                ray = make_ray(o, d, tmax);
+                node_base = sv.tlas_base;
+            }
+            if (st.sp == 0) break;
+            cur = st.pop();
         }
     }
+    return hit;
 }
 
 // ---- barycentrics -----------------------------------------------------------------
