@@ -77,25 +77,32 @@ constexpr int kLdsStack = 24;
 constexpr int kDeepStack = 160;
 
 struct LdsStack {
-    uint32_t* base; // &shared[thread], stride 256 entries
+    uint32_t* base; // &shared[thread], stride 256 entries, limit + 1 rows
     int sp, limit;
     bool overflow;
-    RDR_DEV void push(uint32_t v) {
-        if (sp < limit) base[sp * 256] = v;
-        else overflow = true;
-        sp += sp < limit ? 1 : 0;
+    // Branch-free conditional push: the store always happens, into row `limit` (a dump row
+    // nobody reads) when there is nothing to push or no room.
+    RDR_DEV void push_if(bool p, uint32_t v) {
+        const bool go = p & (sp < limit);
+        base[(go ? sp : limit) * 256] = v;
+        overflow |= p & !go;
+        sp += go ? 1 : 0;
     }
+    RDR_DEV void push(uint32_t v) { push_if(true, v); }
     RDR_DEV uint32_t pop() { return base[--sp * 256]; }
 };
 
 struct DeepStack {
-    uint32_t data[kDeepStack];
+    uint32_t data[kDeepStack + 1];
     int sp;
     bool overflow;
-    RDR_DEV void push(uint32_t v) {
-        if (sp < kDeepStack) data[sp++] = v;
-        else overflow = true;
+    RDR_DEV void push_if(bool p, uint32_t v) {
+        const bool go = p & (sp < kDeepStack);
+        data[go ? sp : kDeepStack] = v;
+        overflow |= p & !go;
+        sp += go ? 1 : 0;
     }
+    RDR_DEV void push(uint32_t v) { push_if(true, v); }
     RDR_DEV uint32_t pop() { return data[--sp]; }
 };
 
@@ -163,16 +170,15 @@ RDR_DEV bool shadow_any_hit(const SceneView& sv, uint32_t own_instance, vec3 o, 
 #pragma unroll
             for (int i = 0; i < kBvhWidth; ++i) {
                 const bool h = (code[i] != kBvhNone) & ray_box(wx[i], wy[i], wz[i], ray.slab, tmin, tmax);
-                if (h) {
-                    if (cur != kBvhNone) st.push(cur);
-                    cur = code[i];
-                }
+                st.push_if(h & (cur != kBvhNone), cur);
+                cur = h ? code[i] : cur;
             }
         } else if (cur != kBvhNone) {
             const uint32_t count = (cur >> 24) & 127u, first = cur & 0xFFFFFFu;
             cur = kBvhNone;
             if (floor >= 0) {
                 const float* tp = sv.blas_tris + (size_t)(tri_base + first) * 9;
+#pragma clang loop vectorize(disable)
                 for (uint32_t i = 0; i < count; ++i, tp += 9)
                     hit |= ray_triangle(ray.o, ray.d, mk3(tp[0], tp[1], tp[2]), mk3(tp[3], tp[4], tp[5]), mk3(tp[6], tp[7], tp[8]), tmin, tmax);
             } else {
@@ -620,7 +626,7 @@ RDR_DEV ListedPixel listed_pixel(const SceneView& sv, const FrameView& fv, uint3
 // apart from the material evaluation so that the pointer-chasing traversal runs at
 // high occupancy with its stack in LDS.  The result is stored per list entry.
 __global__ __launch_bounds__(256) void k_shadow(SceneView sv, FrameView fv) {
-    __shared__ uint32_t stack_mem[kLdsStack * 256];
+    __shared__ uint32_t stack_mem[(kLdsStack + 1) * 256];
     const uint32_t entry = blockIdx.x * 256u + threadIdx.x;
     if (entry >= fv.counters->pixel_count) return;
     const ListedPixel p = listed_pixel(sv, fv, entry);
