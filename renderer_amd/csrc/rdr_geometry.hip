@@ -564,9 +564,10 @@ RDR_DEV SnapVert snap_clip_vert(const ClipVert& v, float half_w, float half_h) {
 
 // ------------------------------------------------------------------------------
 // Tile path: clipped, large or pixel-heavy triangles.
-//   k_tile_setup  clip -> fan -> snap -> SetupTri records, count triangles per 64x64 tile
+//   k_tile_setup  clip -> fan -> snap -> SetupTri records
+//   k_tile_bin<0> count the records per 64x64 tile
 //   k_tile_scan   prefix sum of the per-tile counts -> bin offsets
-//   k_tile_fill   write each record's index into the bins of the tiles it touches
+//   k_tile_bin<1> write each record's index into the bins of the tiles it touches
 //   k_tile_raster one workgroup per tile: bins staged through LDS in batches, each
 //                 thread owns a 4x4 pixel block whose 16 keys stay in registers, then
 //                 one read-min-write of the tile (no atomics: the tile has one owner
@@ -713,9 +714,55 @@ __global__ __launch_bounds__(256) void k_tile_setup(SceneView sv, FrameView fv) 
             t.id = id; t.draw_id = draw_id; t.masked = masked ? 1u : 0u;
             fv.setup[slot] = t;
             if (masked) fv.setup_mask[slot] = mk;
-            for (uint32_t ty = t.py0 / kTile; ty <= t.py1 / kTile; ++ty)
-                for (uint32_t tx = t.px0 / kTile; tx <= t.px1 / kTile; ++tx)
-                    if (tile_touched(t, tx, ty)) atomicAdd(&fv.tile_count[ty * fv.tiles_x + tx], 1u);
+        }
+    }
+}
+
+// Visit every (record, tile) pair where the record may cover a pixel of the tile.  A lane
+// walks the tiles of its own record while there are at most kLaneTiles of them; records
+// spanning more tiles are taken one at a time by the whole wave, 64 tiles per step, so
+// that a full-screen triangle costs tens of steps rather than thousands.  FILL = false
+// counts per tile, FILL = true writes the record index into the tile's bin.
+constexpr uint32_t kLaneTiles = 4;
+
+template <bool FILL>
+RDR_DEV void bin_visit(const FrameView& fv, const SetupTri& t, uint32_t record, uint32_t tx, uint32_t ty) {
+    if (!tile_touched(t, tx, ty)) return;
+    const uint32_t tile = ty * fv.tiles_x + tx;
+    if (FILL) {
+        const uint32_t slot = fv.tile_offset[tile] + atomicAdd(&fv.tile_cursor[tile], 1u);
+        if (slot < fv.bin_capacity) fv.bin_entries[slot] = record;
+    } else {
+        atomicAdd(&fv.tile_count[tile], 1u);
+    }
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_tile_bin(FrameView fv) {
+    const uint32_t lane = lane_id();
+    const uint32_t count = min(fv.counters->setup_count, fv.setup_capacity);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t base_i = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base_i < count; base_i += stride) {
+        const uint32_t i = base_i + lane;
+        uint32_t tx0 = 0, ty0 = 0, tw = 0, n_tiles = 0;
+        SetupTri t;
+        if (i < count) {
+            t = fv.setup[i];
+            tx0 = t.px0 / kTile; ty0 = t.py0 / kTile;
+            tw = t.px1 / kTile - tx0 + 1u;
+            n_tiles = tw * (t.py1 / kTile - ty0 + 1u);
+        }
+        if (n_tiles <= kLaneTiles)
+            for (uint32_t q = 0; q < n_tiles; ++q) bin_visit<FILL>(fv, t, i, tx0 + q % tw, ty0 + q / tw);
+        unsigned long long wide = __ballot(n_tiles > kLaneTiles);
+        while (wide) {
+            const int src = __ffsll((long long)wide) - 1;
+            wide &= wide - 1ull;
+            const uint32_t record = base_i + (uint32_t)src;
+            const SetupTri w = fv.setup[record]; // the same address in every lane: one broadcast load
+            const uint32_t wx0 = w.px0 / kTile, wy0 = w.py0 / kTile, ww = w.px1 / kTile - wx0 + 1u;
+            const uint32_t wn = ww * (w.py1 / kTile - wy0 + 1u);
+            for (uint32_t q = lane; q < wn; q += 64u) bin_visit<FILL>(fv, w, record, wx0 + q % ww, wy0 + q / ww);
         }
     }
 }
@@ -744,20 +791,6 @@ __global__ __launch_bounds__(1024) void k_tile_scan(FrameView fv) {
     if (threadIdx.x == 1023) {
         fv.counters->bin_total = partial[1023];
         if (partial[1023] > fv.bin_capacity) fv.counters->bin_overflow = 1u;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_tile_fill(FrameView fv) {
-    const uint32_t count = min(fv.counters->setup_count, fv.setup_capacity);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-        const SetupTri t = fv.setup[i];
-        for (uint32_t ty = t.py0 / kTile; ty <= t.py1 / kTile; ++ty)
-            for (uint32_t tx = t.px0 / kTile; tx <= t.px1 / kTile; ++tx)
-                if (tile_touched(t, tx, ty)) {
-                    const uint32_t tile = ty * fv.tiles_x + tx;
-                    const uint32_t slot = fv.tile_offset[tile] + atomicAdd(&fv.tile_cursor[tile], 1u);
-                    if (slot < fv.bin_capacity) fv.bin_entries[slot] = i;
-                }
     }
 }
 
@@ -918,8 +951,9 @@ int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t st
         hipLaunchKernelGGL(k_raster<true>, dim3(fv.grid.raster_mask_blocks), dim3(64), 0, stream, sv, fv);
         if (ev) RDR_HIP(hipEventRecord(ev[4], stream));
         hipLaunchKernelGGL(k_tile_setup, dim3(256), dim3(256), 0, stream, sv, fv);
+        hipLaunchKernelGGL(k_tile_bin<false>, dim3(512), dim3(256), 0, stream, fv);
         hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, fv);
-        hipLaunchKernelGGL(k_tile_fill, dim3(256), dim3(256), 0, stream, fv);
+        hipLaunchKernelGGL(k_tile_bin<true>, dim3(512), dim3(256), 0, stream, fv);
         hipLaunchKernelGGL(k_tile_raster, dim3(fv.grid.deferred_blocks), dim3(256), 0, stream, sv, fv);
         if (ev) RDR_HIP(hipEventRecord(ev[5], stream));
     }
