@@ -76,6 +76,8 @@ struct rdr_renderer {
     DeviceBuffer<DeferredTriangle> deferred;
     DeviceBuffer<SetupTri> setup;
     DeviceBuffer<SetupMask> setup_mask;
+    DeviceBuffer<SetupTri> mid;
+    DeviceBuffer<SetupMask> mid_mask;
     DeviceBuffer<uint32_t> tile_count, tile_offset, tile_cursor, bin_entries;
     DeviceBuffer<uint32_t> resolve_out;
     DeviceBuffer<float> srgb_lut;
@@ -114,6 +116,7 @@ struct rdr_renderer {
     uint32_t row_lo = 0, row_hi = 0xFFFFFFFFu;
     uint32_t meshlet_visibility_count = 0;
     uint32_t lds_stack_limit = 24;
+    uint32_t lane_max_pixels = kLaneMaxPixels, mid_max_pixels = kMidMaxPixels;
     uint32_t masked_meshlets = 0; // LOD0 meshlet instances of alpha-masked draws
     rdr_stats stats{};
 };
@@ -327,6 +330,11 @@ FrameView make_frame_view(rdr_renderer* r) {
     fv.tile_cursor = r->tile_cursor.ptr;
     fv.bin_entries = r->bin_entries.ptr;
     fv.setup_capacity = (uint32_t)r->setup.count;
+    fv.mid = r->mid.ptr;
+    fv.mid_mask = r->mid_mask.ptr;
+    fv.mid_capacity = (uint32_t)r->mid.count;
+    fv.lane_max_pixels = r->lane_max_pixels;
+    fv.mid_max_pixels = r->mid_max_pixels;
     fv.bin_capacity = (uint32_t)r->bin_entries.count;
     fv.tiles_x = (r->width + 63u) / 64u;
     fv.tiles_y = (r->height + 63u) / 64u;
@@ -337,12 +345,14 @@ FrameView make_frame_view(rdr_renderer* r) {
     g.raster_blocks = std::max(1u, std::min(fv.visible_capacity, 256u * 32u));
     g.raster_mask_blocks = std::max(1u, std::min(r->masked_meshlets, 256u * 16u));
     g.deferred_blocks = fv.tiles_x * fv.tiles_y; // one workgroup per 64x64 tile
+    g.mid_blocks = 2048;
     g.shade_blocks_x = (r->width + 15u) / 16u;
     g.shade_blocks_y = (fv.row_hi - fv.row_lo + 15u) / 16u;
     g.slot_draw = 0;
     g.slot_cull = g.slot_draw + g.draw_blocks;
     g.slot_raster = g.slot_cull + g.cull_blocks * kCullSlots;
-    g.slot_deferred = g.slot_raster + (g.raster_blocks + g.raster_mask_blocks) * kRasterSlots;
+    g.slot_mid = g.slot_raster + (g.raster_blocks + g.raster_mask_blocks) * kRasterSlots;
+    g.slot_deferred = g.slot_mid + g.mid_blocks;
     g.slot_shade = g.slot_deferred + g.deferred_blocks;
     g.slot_total = g.slot_shade;
     return fv;
@@ -351,7 +361,7 @@ FrameView make_frame_view(rdr_renderer* r) {
 int fetch_counters(rdr_renderer* r, FrameCounters* out) {
     RDR_HIP(hipStreamSynchronize(r->stream));
     RDR_HIP(hipMemcpy(out, r->counters.ptr, sizeof(FrameCounters), hipMemcpyDeviceToHost));
-    RDR_CHECK(out->deferred_overflow == 0 && out->setup_overflow == 0 && out->bin_overflow == 0,
+    RDR_CHECK(out->deferred_overflow == 0 && out->setup_overflow == 0 && out->bin_overflow == 0 && out->mid_overflow == 0,
               "frame: a tile-path list (deferred triangles, setup records or bins) overflowed; triangles were dropped");
     RDR_CHECK(out->cmd_count <= r->commands.count && (uint64_t)out->vis_count + out->vis_mask_count <= r->visible.count,
               "frame: a work list overflowed");
@@ -383,6 +393,9 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
     r->width = width; r->height = height; r->device = hip_devices[0];
     if (const char* e = std::getenv("RDR_DEBUG_STACK_LIMIT")) // test hook: force the deep-stack shadow path
         r->lds_stack_limit = (uint32_t)std::min(24, std::max(1, std::atoi(e)));
+    // tuning hooks: bounding-box pixel counts at which k_raster hands a triangle to k_mid_raster / the tile path
+    if (const char* e = std::getenv("RDR_LANE_MAX_PIXELS")) r->lane_max_pixels = (uint32_t)std::min(4096, std::max(1, std::atoi(e)));
+    if (const char* e = std::getenv("RDR_MID_MAX_PIXELS")) r->mid_max_pixels = (uint32_t)std::min(4096, std::max(1, std::atoi(e)));
     RDR_HIP(hipSetDevice(r->device));
     RDR_HIP(hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking));
     r->stream = r->own_stream;
@@ -485,7 +498,8 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
         // tile path: deferred clip-space triangles, their screen-space records (clipping can fan one
         // triangle into several) and the per-tile bins
         const size_t n_def = (size_t)std::min<uint64_t>(std::max<uint64_t>(tri_total, 1u << 16), 1u << 21);
-        if (r->deferred.alloc(n_def) || r->setup.alloc(n_def + n_def / 2) || r->setup_mask.alloc(n_def + n_def / 2)) return 1;
+        if (r->deferred.alloc(n_def) || r->setup.alloc(n_def + n_def / 2) || r->setup_mask.alloc(n_def + n_def / 2) ||
+            r->mid.alloc(n_def) || r->mid_mask.alloc(n_def)) return 1;
         if (r->bin_entries.alloc(std::max<size_t>(n_def * 4, (size_t)1 << 22))) return 1;
     }
     {
@@ -688,6 +702,7 @@ int rdr_get_stats(rdr_renderer* r, rdr_stats* out) {
             st.triangles_tested += p[0]; st.triangles_rasterised += p[1]; st.triangles_big += p[2];
             st.fragments += p[3]; st.vertices_transformed += p[4];
         }
+        for (uint32_t b = 0; b < g.mid_blocks; ++b) st.fragments += slots[g.slot_mid + b];
         for (uint32_t b = 0; b < g.deferred_blocks; ++b) st.fragments += slots[g.slot_deferred + b];
         if (r->shaded) st.pixels_covered = fc.pixel_count;
     }

@@ -21,8 +21,7 @@
 namespace {
 
 constexpr float kGuardBand = 8.0f;
-constexpr int kSmallExtent = 64 * 256; // bounding boxes up to 64 px on a side are candidates for the per-lane scan (int32 exact)
-constexpr int kLaneMaxPixels = 512;    // ... if they hold at most this many pixels; everything else goes to the tile path
+constexpr int kSmallExtent = 64 * 256; // bounding boxes up to 64 px on a side stay in k_raster / k_mid_raster (int32 exact); see FrameView::lane_max_pixels
 constexpr int kTile = 64;              // screen tile of the binned path, pixels
 constexpr int kTileBatch = 64;         // triangle records staged in LDS per round
 
@@ -371,6 +370,52 @@ RDR_DEV uint32_t scan_lane(const SceneView& sv, const FrameView& fv, const TriSe
     return frags;
 }
 
+// Orient, face-cull and box a snapped triangle. Returns false when nothing can be covered.
+RDR_DEV bool make_setup(const FrameView& fv, SnapVert v0, SnapVert v1, SnapVert v2, bool cull_front, SetupTri& t, SetupMask& mk) {
+    long long A = (long long)(v1.X - v0.X) * (v2.Y - v0.Y) - (long long)(v1.Y - v0.Y) * (v2.X - v0.X);
+    if (A == 0) return false;
+    if (A > 0) {
+        if (cull_front) return false; // clockwise on the y-down screen: front-facing, culled in the opaque pipeline
+    } else {
+        const SnapVert tmp = v1; v1 = v2; v2 = tmp;
+        A = -A;
+    }
+    const int32_t minX = min(v0.X, min(v1.X, v2.X)), maxX = max(v0.X, max(v1.X, v2.X));
+    const int32_t minY = min(v0.Y, min(v1.Y, v2.Y)), maxY = max(v0.Y, max(v1.Y, v2.Y));
+    const int px0 = max((minX - 128 + 255) >> 8, 0), px1 = min((maxX - 128) >> 8, (int)fv.width - 1);
+    const int py0 = max((minY - 128 + 255) >> 8, 0), py1 = min((maxY - 128) >> 8, (int)fv.height - 1);
+    if (px0 > px1 || py0 > py1) return false;
+    t.X0 = v0.X; t.Y0 = v0.Y; t.X1 = v1.X; t.Y1 = v1.Y; t.X2 = v2.X; t.Y2 = v2.Y;
+    t.z0 = v0.z; t.dz1 = v1.z - v0.z; t.dz2 = v2.z - v0.z;
+    t.inv_area = 1.0f / (float)A;
+    t.px0 = (uint16_t)px0; t.py0 = (uint16_t)py0; t.px1 = (uint16_t)px1; t.py1 = (uint16_t)py1;
+    t._pad = 0;
+    mk.inv_w[0] = v0.inv_w; mk.inv_w[1] = v1.inv_w; mk.inv_w[2] = v2.inv_w;
+    const SnapVert* vs[3] = {&v0, &v1, &v2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { mk.uv[k][0] = vs[k]->u0; mk.uv[k][1] = vs[k]->v0; mk.uv[k][2] = vs[k]->u1; mk.uv[k][3] = vs[k]->v1; }
+    mk._pad = 0;
+    return true;
+}
+
+// The whole wave scans the bounding box, 8x8 pixels per step.
+template <typename I, bool MASK>
+RDR_DEV uint32_t scan_wave(const SceneView& sv, const FrameView& fv, const TriSetup<I>& t, const AlphaTest& at, uint32_t id, uint32_t lane) {
+    const int bw = t.px1 - t.px0 + 1, bh = t.py1 - t.py0 + 1;
+    const int stamps_x = (bw + 7) >> 3, stamps = stamps_x * ((bh + 7) >> 3);
+    uint32_t frags = 0;
+    for (int sidx = 0; sidx < stamps; ++sidx) {
+        const int px = t.px0 + (sidx % stamps_x) * 8 + (int)(lane & 7u);
+        const int py = t.py0 + (sidx / stamps_x) * 8 + (int)(lane >> 3);
+        if (px <= t.px1 && py <= t.py1) {
+            I e01, e12, e20;
+            edges_at<I>(t, px, py, e01, e12, e20);
+            frags += shade_sample<I, MASK>(sv, fv, t, at, px, py, e01, e12, e20, id);
+        }
+    }
+    return frags;
+}
+
 // Per-wave LDS: the transformed vertices of one meshlet.
 struct MeshletLds {
     float cx[64], cy[64], cz[64], cw[64]; // clip space
@@ -427,7 +472,28 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
         for (uint32_t t0 = 0; t0 < m.triangle_count; t0 += 64) {
             const uint32_t ti = t0 + lane;
             bool defer = false; // clipped, large or pixel-heavy triangles go to the tile path
+            bool mid = false;   // too many pixels for one lane: queued for k_mid_raster
             uint32_t ia = 0, ib = 0, ic = 0;
+            // snapped vertices of the triangle with meshlet-local vertices (a, b, c), from the wave's LDS
+            auto load_snap = [&](uint32_t a, uint32_t b, uint32_t c, SnapVert& s0, SnapVert& s1, SnapVert& s2) {
+                s0.X = lds.X[a]; s0.Y = lds.Y[a]; s0.z = lds.z[a];
+                s1.X = lds.X[b]; s1.Y = lds.Y[b]; s1.z = lds.z[b];
+                s2.X = lds.X[c]; s2.Y = lds.Y[c]; s2.z = lds.z[c];
+                s0.inv_w = s1.inv_w = s2.inv_w = 0.0f;
+                s0.u0 = s0.v0 = s0.u1 = s0.v1 = 0.0f;
+                s1.u0 = s1.v0 = s1.u1 = s1.v1 = 0.0f;
+                s2.u0 = s2.v0 = s2.u1 = s2.v1 = 0.0f;
+                if (MASK && at.has_tex) { // the alpha test needs perspective-correct uv
+                    const uint32_t* mv = sv.meshlet_vertices + m.vertex_offset;
+                    const rdr_vertex* va = &sv.vertices[mv[a] + mesh_vertex_offset];
+                    const rdr_vertex* vb = &sv.vertices[mv[b] + mesh_vertex_offset];
+                    const rdr_vertex* vc = &sv.vertices[mv[c] + mesh_vertex_offset];
+                    s0.inv_w = 1.0f / lds.cw[a]; s1.inv_w = 1.0f / lds.cw[b]; s2.inv_w = 1.0f / lds.cw[c];
+                    s0.u0 = va->uv[0]; s0.v0 = va->uv[1]; s0.u1 = va->uv[2]; s0.v1 = va->uv[3];
+                    s1.u0 = vb->uv[0]; s1.v0 = vb->uv[1]; s1.u1 = vb->uv[2]; s1.v1 = vb->uv[3];
+                    s2.u0 = vc->uv[0]; s2.v0 = vc->uv[1]; s2.u1 = vc->uv[2]; s2.v1 = vc->uv[3];
+                }
+            };
             if (ti < m.triangle_count) {
                 const uint8_t* tp = sv.meshlet_triangles + m.triangle_offset + ti * 3;
                 ia = tp[0]; ib = tp[1]; ic = tp[2];
@@ -452,29 +518,40 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
                         defer = ex > kSmallExtent || ey > kSmallExtent;
                         if (!defer) {
                             SnapVert s0, s1, s2;
-                            s0.X = X0; s0.Y = Y0; s0.z = lds.z[ia];
-                            s1.X = X1; s1.Y = Y1; s1.z = lds.z[ib];
-                            s2.X = X2; s2.Y = Y2; s2.z = lds.z[ic];
-                            s0.inv_w = s1.inv_w = s2.inv_w = 0.0f;
-                            s0.u0 = s0.v0 = s0.u1 = s0.v1 = 0.0f;
-                            s1.u0 = s1.v0 = s1.u1 = s1.v1 = 0.0f;
-                            s2.u0 = s2.v0 = s2.u1 = s2.v1 = 0.0f;
-                            if (MASK && at.has_tex) { // the alpha test needs perspective-correct uv
-                                const uint32_t* mv = sv.meshlet_vertices + m.vertex_offset;
-                                const rdr_vertex* va = &sv.vertices[mv[ia] + mesh_vertex_offset];
-                                const rdr_vertex* vb = &sv.vertices[mv[ib] + mesh_vertex_offset];
-                                const rdr_vertex* vc = &sv.vertices[mv[ic] + mesh_vertex_offset];
-                                s0.inv_w = 1.0f / lds.cw[ia]; s1.inv_w = 1.0f / lds.cw[ib]; s2.inv_w = 1.0f / lds.cw[ic];
-                                s0.u0 = va->uv[0]; s0.v0 = va->uv[1]; s0.u1 = va->uv[2]; s0.v1 = va->uv[3];
-                                s1.u0 = vb->uv[0]; s1.v0 = vb->uv[1]; s1.u1 = vb->uv[2]; s1.v1 = vb->uv[3];
-                                s2.u0 = vc->uv[0]; s2.v0 = vc->uv[1]; s2.u1 = vc->uv[2]; s2.v1 = vc->uv[3];
-                            }
+                            load_snap(ia, ib, ic, s0, s1, s2);
                             const TriSetup<int32_t> ts = setup_triangle<int32_t>(fv, s0, s1, s2, cull_front);
                             if (ts.valid) {
                                 const int npx = (ts.px1 - ts.px0 + 1) * (ts.py1 - ts.py0 + 1);
-                                defer = npx > kLaneMaxPixels;
-                                if (!defer) st_frags += scan_lane<int32_t, MASK>(sv, fv, ts, at, (vm.instance << 7) | ti);
+                                defer = npx > (int)fv.mid_max_pixels;
+                                mid = !defer && npx > (int)fv.lane_max_pixels;
+                                if (!defer && !mid) st_frags += scan_lane<int32_t, MASK>(sv, fv, ts, at, (vm.instance << 7) | ti);
                             }
+                        }
+                    }
+                }
+            }
+            // mid-sized triangles: queue their scan set-up, slots reserved with one atomic per wave
+            {
+                const unsigned long long mm = __ballot(mid);
+                if (mm) {
+                    const int leader = __ffsll((long long)mm) - 1;
+                    uint32_t base = 0;
+                    if ((int)lane == leader) base = atomicAdd(&fv.counters->mid_count, (uint32_t)__popcll(mm));
+                    base = __shfl(base, leader, 64);
+                    if (mid) {
+                        const uint32_t slot = base + ballot_rank(mm);
+                        if (slot < fv.mid_capacity) {
+                            SnapVert s0, s1, s2;
+                            load_snap(ia, ib, ic, s0, s1, s2);
+                            SetupTri t;
+                            SetupMask mk;
+                            make_setup(fv, s0, s1, s2, cull_front, t, mk);
+                            t.id = (vm.instance << 7) | ti; t.draw_id = vm.draw_id;
+                            t.masked = (MASK && at.has_tex) ? 1u : 0u;
+                            fv.mid[slot] = t;
+                            if (MASK && at.has_tex) fv.mid_mask[slot] = mk;
+                        } else {
+                            atomicAdd(&fv.counters->mid_overflow, 1u);
                         }
                     }
                 }
@@ -520,6 +597,57 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
             uint32_t* slot = fv.stat_slots + fv.grid.slot_raster + (blockIdx.x + (MASK ? fv.grid.raster_blocks : 0u)) * kRasterSlots;
             slot[0] = a; slot[1] = b; slot[2] = c; slot[3] = f; slot[4] = v;
         }
+    }
+}
+
+// Mid-sized triangles queued by k_raster: one wave per record, every lane one pixel of each
+// 8x8 stamp, fragments merged with the same atomic as the per-lane scan.  Spreads the pixel
+// work of a meshlet that covers a lot of screen over many waves.
+__global__ __launch_bounds__(256) void k_mid_raster(SceneView sv, FrameView fv) {
+    __shared__ uint32_t wg_frags[4];
+    const uint32_t lane = lane_id();
+    const uint32_t count = min(fv.counters->mid_count, fv.mid_capacity);
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    uint32_t frags = 0;
+    for (uint32_t r = wave; r < count; r += n_waves) {
+        const SetupTri t = fv.mid[r]; // the same address in every lane: one broadcast load
+        TriSetup<int32_t> ts;
+        ts.v0 = SnapVert{}; ts.v1 = SnapVert{}; ts.v2 = SnapVert{};
+        ts.v0.X = t.X0; ts.v0.Y = t.Y0; ts.v1.X = t.X1; ts.v1.Y = t.Y1; ts.v2.X = t.X2; ts.v2.Y = t.Y2;
+        ts.v0.z = t.z0;
+        ts.dx01 = t.X1 - t.X0; ts.dy01 = t.Y1 - t.Y0;
+        ts.dx12 = t.X2 - t.X1; ts.dy12 = t.Y2 - t.Y1;
+        ts.dx20 = t.X0 - t.X2; ts.dy20 = t.Y0 - t.Y2;
+        ts.bias01 = (ts.dy01 < 0 || (ts.dy01 == 0 && ts.dx01 > 0)) ? 0 : -1;
+        ts.bias12 = (ts.dy12 < 0 || (ts.dy12 == 0 && ts.dx12 > 0)) ? 0 : -1;
+        ts.bias20 = (ts.dy20 < 0 || (ts.dy20 == 0 && ts.dx20 > 0)) ? 0 : -1;
+        ts.inv_area = t.inv_area; ts.dz1 = t.dz1; ts.dz2 = t.dz2;
+        ts.px0 = t.px0; ts.py0 = t.py0; ts.px1 = t.px1; ts.py1 = t.py1;
+        ts.valid = true;
+        const rdr_mesh_draw d = sv.draws[t.draw_id];
+        if (d.alpha_mode == 1u) {
+            const AlphaTest at = make_alpha_test(sv, d);
+            if (t.masked) {
+                const SetupMask* mk = &fv.mid_mask[r];
+                SnapVert* vs[3] = {&ts.v0, &ts.v1, &ts.v2};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    vs[k]->inv_w = mk->inv_w[k];
+                    vs[k]->u0 = mk->uv[k][0]; vs[k]->v0 = mk->uv[k][1]; vs[k]->u1 = mk->uv[k][2]; vs[k]->v1 = mk->uv[k][3];
+                }
+            }
+            frags += scan_wave<int32_t, true>(sv, fv, ts, at, t.id, lane);
+        } else {
+            AlphaTest at;
+            at.enabled = false; at.has_tex = false;
+            frags += scan_wave<int32_t, false>(sv, fv, ts, at, t.id, lane);
+        }
+    }
+    if (fv.collect_stats) {
+        const uint32_t f = wave_sum(frags);
+        if (lane == 0) wg_frags[threadIdx.x >> 6] = f;
+        __syncthreads();
+        if (threadIdx.x == 0) fv.stat_slots[fv.grid.slot_mid + blockIdx.x] = wg_frags[0] + wg_frags[1] + wg_frags[2] + wg_frags[3];
     }
 }
 
@@ -608,34 +736,6 @@ RDR_DEV bool tile_touched(const SetupTri& t, uint32_t tx, uint32_t ty) {
     const EdgeEq e20 = make_edge(t.X2, t.Y2, t.X0, t.Y0, x0, y0);
     return edge_max(e01, kTile - 1, kTile - 1) + e01.bias >= 0 && edge_max(e12, kTile - 1, kTile - 1) + e12.bias >= 0 &&
            edge_max(e20, kTile - 1, kTile - 1) + e20.bias >= 0;
-}
-
-// Orient, face-cull and box a snapped triangle. Returns false when nothing can be covered.
-RDR_DEV bool make_setup(const FrameView& fv, SnapVert v0, SnapVert v1, SnapVert v2, bool cull_front, SetupTri& t, SetupMask& mk) {
-    long long A = (long long)(v1.X - v0.X) * (v2.Y - v0.Y) - (long long)(v1.Y - v0.Y) * (v2.X - v0.X);
-    if (A == 0) return false;
-    if (A > 0) {
-        if (cull_front) return false; // clockwise on the y-down screen: front-facing, culled in the opaque pipeline
-    } else {
-        const SnapVert tmp = v1; v1 = v2; v2 = tmp;
-        A = -A;
-    }
-    const int32_t minX = min(v0.X, min(v1.X, v2.X)), maxX = max(v0.X, max(v1.X, v2.X));
-    const int32_t minY = min(v0.Y, min(v1.Y, v2.Y)), maxY = max(v0.Y, max(v1.Y, v2.Y));
-    const int px0 = max((minX - 128 + 255) >> 8, 0), px1 = min((maxX - 128) >> 8, (int)fv.width - 1);
-    const int py0 = max((minY - 128 + 255) >> 8, 0), py1 = min((maxY - 128) >> 8, (int)fv.height - 1);
-    if (px0 > px1 || py0 > py1) return false;
-    t.X0 = v0.X; t.Y0 = v0.Y; t.X1 = v1.X; t.Y1 = v1.Y; t.X2 = v2.X; t.Y2 = v2.Y;
-    t.z0 = v0.z; t.dz1 = v1.z - v0.z; t.dz2 = v2.z - v0.z;
-    t.inv_area = 1.0f / (float)A;
-    t.px0 = (uint16_t)px0; t.py0 = (uint16_t)py0; t.px1 = (uint16_t)px1; t.py1 = (uint16_t)py1;
-    t._pad = 0;
-    mk.inv_w[0] = v0.inv_w; mk.inv_w[1] = v1.inv_w; mk.inv_w[2] = v2.inv_w;
-    const SnapVert* vs[3] = {&v0, &v1, &v2};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { mk.uv[k][0] = vs[k]->u0; mk.uv[k][1] = vs[k]->v0; mk.uv[k][2] = vs[k]->u1; mk.uv[k][3] = vs[k]->v1; }
-    mk._pad = 0;
-    return true;
 }
 
 __global__ __launch_bounds__(256) void k_tile_setup(SceneView sv, FrameView fv) {
@@ -949,6 +1049,7 @@ int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t st
         if (ev) RDR_HIP(hipEventRecord(ev[3], stream));
         hipLaunchKernelGGL(k_raster<false>, dim3(fv.grid.raster_blocks), dim3(64), 0, stream, sv, fv);
         hipLaunchKernelGGL(k_raster<true>, dim3(fv.grid.raster_mask_blocks), dim3(64), 0, stream, sv, fv);
+        hipLaunchKernelGGL(k_mid_raster, dim3(fv.grid.mid_blocks), dim3(256), 0, stream, sv, fv);
         if (ev) RDR_HIP(hipEventRecord(ev[4], stream));
         hipLaunchKernelGGL(k_tile_setup, dim3(256), dim3(256), 0, stream, sv, fv);
         hipLaunchKernelGGL(k_tile_bin<false>, dim3(512), dim3(256), 0, stream, fv);

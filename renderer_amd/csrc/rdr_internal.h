@@ -91,7 +91,9 @@ struct FrameCounters {
     uint32_t bin_total;       // tile-bin entries needed this frame
     uint32_t bin_overflow;
     uint32_t vis_mask_count;  // alpha-masked meshlets, stored from the back of `visible`
-    uint32_t _pad0[5];
+    uint32_t mid_count;       // SetupTri records queued for k_mid_raster
+    uint32_t mid_overflow;
+    uint32_t _pad0[3];
     unsigned long long _pad1[16];
 };
 static_assert(sizeof(FrameCounters) == 192, "FrameCounters layout");
@@ -132,6 +134,7 @@ struct BvhWide {
     uint16_t box[3][kBvhWidth][2]; // [axis][child][min, max]
 };
 static_assert(sizeof(BvhWide) == kBvhWidth * 16, "BvhWide layout");
+constexpr uint32_t kLaneMaxPixels = 16, kMidMaxPixels = 1024; // defaults of the routing thresholds
 constexpr uint32_t kBvhNone = 0xFFFFFFFFu;
 constexpr uint32_t kBvhLeaf = 0x80000000u;
 constexpr uint32_t kBvhMaxLeaf = 127u;
@@ -175,8 +178,8 @@ struct SceneView {
 
 // Launch geometry of one frame and where each kernel's workgroups put their statistics.
 struct GridPlan {
-    uint32_t draw_blocks, cull_blocks, raster_blocks, raster_mask_blocks, deferred_blocks, shade_blocks_x, shade_blocks_y;
-    uint32_t slot_draw, slot_cull, slot_raster, slot_deferred, slot_shade, slot_total;
+    uint32_t draw_blocks, cull_blocks, raster_blocks, raster_mask_blocks, mid_blocks, deferred_blocks, shade_blocks_x, shade_blocks_y;
+    uint32_t slot_draw, slot_cull, slot_raster, slot_mid, slot_deferred, slot_shade, slot_total;
 };
 constexpr uint32_t kCullSlots = 4, kRasterSlots = 8;
 
@@ -202,6 +205,14 @@ struct FrameView {
     uint32_t* tile_cursor; // per tile: fill cursor
     uint32_t* bin_entries; // SetupTri indices grouped by tile
     uint32_t setup_capacity, bin_capacity, tiles_x, tiles_y;
+    SetupTri* mid;        // scan set-ups of mid-sized triangles (k_raster -> k_mid_raster)
+    SetupMask* mid_mask;
+    uint32_t mid_capacity;
+    // Routing of a triangle whose bounding box is at most 64 px on a side, by the pixels in
+    // the box: up to lane_max_pixels one lane of k_raster scans it, up to mid_max_pixels it is
+    // queued for k_mid_raster (a wave per triangle, 8x8 pixels per step), beyond that (and
+    // for larger or clipped triangles) it goes to the tile path.
+    uint32_t lane_max_pixels, mid_max_pixels;
     uint32_t lds_stack_limit; // entries of the LDS traversal stack in use (<= 24; lowered only by tests)
     // Per-workgroup statistics: every workgroup stores its partial counts in its own
     // slot with plain stores (no contended atomics); the host sums the slots on request.
