@@ -388,6 +388,10 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
     RDR_HIP(hipGetDeviceCount(&count));
     RDR_CHECK(count > 0, "rdr_create: no HIP device available; this library has no CPU path");
     RDR_CHECK(hip_devices[0] >= 0 && hip_devices[0] < count, "rdr_create: HIP device index out of range");
+    for (uint32_t b = 0; b < 256; ++b) { // the texel decode's division-free b / 255 must be exact
+        const float c = 0x1.010102p-8f, x = (float)b, q = x * c;
+        RDR_CHECK(std::fmaf(std::fmaf(-255.0f, q, x), c, q) == x / 255.0f, "rdr_create: unorm8 self-check failed");
+    }
     std::unique_ptr<rdr_renderer> r(new rdr_renderer());
     if (cfg) r->cfg = *cfg;
     r->width = width; r->height = height; r->device = hip_devices[0];

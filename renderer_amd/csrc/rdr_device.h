@@ -105,6 +105,15 @@ RDR_DEV uint32_t mip_dim(uint32_t d, uint32_t level) {
     return v ? v : 1u;
 }
 
+// b / 255.0f for a byte value, bit-exact, without the IEEE division sequence: one
+// Newton step on b * fl(1/255) is correctly rounded for all 256 inputs (rdr_create
+// checks this on the host, whose fmaf rounds like the device's).
+RDR_DEV float unorm8(uint32_t b) {
+    const float c = 0x1.010102p-8f; // fl(1 / 255)
+    const float x = (float)b, q = x * c;
+    return fmaf(fmaf(-255.0f, q, x), c, q);
+}
+
 RDR_DEV vec4 decode_texel(const uint8_t* p, uint32_t format, const float* srgb_lut) {
     if (format == RDR_FORMAT_RGBA32F) {
         const float4 f = *reinterpret_cast<const float4*>(p);
@@ -113,8 +122,8 @@ RDR_DEV vec4 decode_texel(const uint8_t* p, uint32_t format, const float* srgb_l
     const uint32_t t = *reinterpret_cast<const uint32_t*>(p);
     const uint32_t r = t & 255u, g = (t >> 8) & 255u, b = (t >> 16) & 255u, a = t >> 24;
     if (format == RDR_FORMAT_RGBA8_SRGB)
-        return mk4(srgb_lut[r], srgb_lut[g], srgb_lut[b], (float)a / 255.0f);
-    return mk4((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f, (float)a / 255.0f);
+        return mk4(srgb_lut[r], srgb_lut[g], srgb_lut[b], unorm8(a));
+    return mk4(unorm8(r), unorm8(g), unorm8(b), unorm8(a));
 }
 
 RDR_DEV vec4 lerp4(vec4 a, vec4 b, float t) {
@@ -123,6 +132,7 @@ RDR_DEV vec4 lerp4(vec4 a, vec4 b, float t) {
 }
 
 RDR_DEV int wrap_repeat(int i, int n) {
+    if ((n & (n - 1)) == 0) return i & (n - 1); // power-of-two extent: the mask is the non-negative remainder
     int m = i % n;
     return m < 0 ? m + n : m;
 }
@@ -164,8 +174,8 @@ RDR_DEV vec4 image_sample_grad(const GpuImage& im, const uint8_t* texels, const 
                                float dudx, float dvdx, float dudy, float dvdy) {
     const float w = (float)im.width, h = (float)im.height;
     const float ax = dudx * w, ay = dvdx * h, bx = dudy * w, by = dvdy * h;
-    const float rx = sqrtf(ax * ax + ay * ay), ry = sqrtf(bx * bx + by * by);
-    const float rho = fmaxf(rx, ry);
+    // max(sqrt(a), sqrt(b)) == sqrt(max(a, b)): the correctly rounded square root is monotonic
+    const float rho = sqrtf(fmaxf(ax * ax + ay * ay, bx * bx + by * by));
     return image_sample_lod(im, texels, lut, u, v, log2f(rho));
 }
 
@@ -227,10 +237,20 @@ RDR_DEV vec4 cube_bilinear(const GpuCubemap& cm, const uint8_t* texels, uint32_t
     const float fx = floorf(x), fy = floorf(y);
     const float ax = x - fx, ay = y - fy;
     const int i0 = (int)fx, j0 = (int)fy;
-    const vec4 t00 = cube_fetch(cm, texels, level, face, i0, j0);
-    const vec4 t10 = cube_fetch(cm, texels, level, face, i0 + 1, j0);
-    const vec4 t01 = cube_fetch(cm, texels, level, face, i0, j0 + 1);
-    const vec4 t11 = cube_fetch(cm, texels, level, face, i0 + 1, j0 + 1);
+    vec4 t00, t10, t01, t11;
+    if (i0 >= 0 && j0 >= 0 && i0 + 1 < n && j0 + 1 < n) { // the whole footprint lies inside the face: one address computation
+        const uint32_t tb = cm.format == RDR_FORMAT_RGBA32F ? 16u : 4u;
+        const uint8_t* p = texels + cm.offset + cm.level_offset[level] + ((size_t)face * n * n + (size_t)j0 * n + i0) * tb;
+        t00 = decode_texel(p, cm.format, nullptr);
+        t10 = decode_texel(p + tb, cm.format, nullptr);
+        t01 = decode_texel(p + (size_t)n * tb, cm.format, nullptr);
+        t11 = decode_texel(p + (size_t)n * tb + tb, cm.format, nullptr);
+    } else {
+        t00 = cube_fetch(cm, texels, level, face, i0, j0);
+        t10 = cube_fetch(cm, texels, level, face, i0 + 1, j0);
+        t01 = cube_fetch(cm, texels, level, face, i0, j0 + 1);
+        t11 = cube_fetch(cm, texels, level, face, i0 + 1, j0 + 1);
+    }
     return lerp4(lerp4(t00, t10, ax), lerp4(t01, t11, ax), ay);
 }
 

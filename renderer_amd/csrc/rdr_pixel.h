@@ -1,0 +1,77 @@
+// rdr_pixel.h — what the shadow pass and the shading pass share: decoding a visibility
+// key, the covered-pixel list entry, and the analytic barycentrics of a pixel inside its
+// triangle (assets/shaders/shading.frag.glsl:81-171).
+#pragma once
+#include "rdr_device.h"
+
+namespace {
+
+// ---- barycentrics -----------------------------------------------------------------
+struct BaryDeriv {
+    vec3 lambda, ddx, ddy;
+};
+
+RDR_DEV BaryDeriv calc_full_bary(vec4 pt0, vec4 pt1, vec4 pt2, float ndcx, float ndcy, float winw, float winh) {
+    BaryDeriv r;
+    const vec3 inv_w = mk3(1.0f / pt0.w, 1.0f / pt1.w, 1.0f / pt2.w);
+    const float n0x = pt0.x * inv_w.x, n0y = pt0.y * inv_w.x;
+    const float n1x = pt1.x * inv_w.y, n1y = pt1.y * inv_w.y;
+    const float n2x = pt2.x * inv_w.z, n2y = pt2.y * inv_w.z;
+    const float ax = n2x - n1x, ay = n2y - n1y, bx = n0x - n1x, by = n0y - n1y;
+    const float inv_det = 1.0f / (ax * by - bx * ay);
+    r.ddx = (mk3(n1y - n2y, n2y - n0y, n0y - n1y) * inv_det) * inv_w;
+    r.ddy = (mk3(n2x - n1x, n0x - n2x, n1x - n0x) * inv_det) * inv_w;
+    float ddx_sum = (r.ddx.x + r.ddx.y) + r.ddx.z;
+    float ddy_sum = (r.ddy.x + r.ddy.y) + r.ddy.z;
+    const float dx = ndcx - n0x, dy = ndcy - n0y;
+    const float interp_inv_w = (inv_w.x + dx * ddx_sum) + dy * ddy_sum;
+    const float interp_w = 1.0f / interp_inv_w;
+    r.lambda.x = interp_w * ((inv_w.x + dx * r.ddx.x) + dy * r.ddy.x);
+    r.lambda.y = interp_w * ((0.0f + dx * r.ddx.y) + dy * r.ddy.y);
+    r.lambda.z = interp_w * ((0.0f + dx * r.ddx.z) + dy * r.ddy.z);
+    const float sx = 2.0f / winw, sy = 2.0f / winh;
+    r.ddx = r.ddx * sx;
+    r.ddy = r.ddy * sy;
+    ddx_sum *= sx;
+    ddy_sum *= sy;
+    r.ddy = r.ddy * -1.0f;
+    ddy_sum *= -1.0f;
+    const float iwx = 1.0f / (interp_inv_w + ddx_sum), iwy = 1.0f / (interp_inv_w + ddy_sum);
+    r.ddx = ((r.lambda * interp_inv_w + r.ddx) * iwx) - r.lambda;
+    r.ddy = ((r.lambda * interp_inv_w + r.ddy) * iwy) - r.lambda;
+    return r;
+}
+
+RDR_DEV vec3 interp3(const BaryDeriv& b, vec3 a0, vec3 a1, vec3 a2) {
+    return mk3(dot3(mk3(a0.x, a1.x, a2.x), b.lambda), dot3(mk3(a0.y, a1.y, a2.y), b.lambda),
+               dot3(mk3(a0.z, a1.z, a2.z), b.lambda));
+}
+
+RDR_DEV vec3 vload3(const float* p) { return mk3(p[0], p[1], p[2]); }
+
+// Decode a visibility key into (draw, meshlet, triangle).
+RDR_DEV void decode_key(const SceneView& sv, unsigned long long key, uint32_t& draw_id, uint32_t& meshlet, uint32_t& tri) {
+    const uint32_t id = (uint32_t)key, instance = id >> 7;
+    tri = id & 127u;
+    draw_id = sv.instance_draw[instance];
+    const rdr_mesh_draw d = sv.draws[draw_id];
+    const rdr_mesh_lod L = sv.meshes[d.mesh_index].lods[sv.draw_lod[draw_id]];
+    meshlet = L.meshlet_offset + (instance - d.meshlet_visibility_offset);
+}
+
+struct ListedPixel {
+    uint32_t pi, draw_id, meshlet, tri;
+    float uvx, uvy;
+};
+
+RDR_DEV ListedPixel listed_pixel(const SceneView& sv, const FrameView& fv, uint32_t entry) {
+    ListedPixel p;
+    p.pi = fv.pixel_list[entry];
+    decode_key(sv, fv.vis[p.pi], p.draw_id, p.meshlet, p.tri);
+    const uint32_t iy = p.pi / fv.width, ix = p.pi - iy * fv.width;
+    p.uvx = ((float)ix + 0.5f) / (float)fv.width;
+    p.uvy = 1.0f - ((float)iy + 0.5f) / (float)fv.height;
+    return p;
+}
+
+} // namespace
