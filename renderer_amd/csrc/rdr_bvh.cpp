@@ -6,6 +6,7 @@
 // draw's model matrix; everything flagged opaque).  Two-level binary BVH with
 // binned-SAH splits; leaves hold up to four triangles stored as bare positions
 // in leaf order so the traversal kernel reads them contiguously.
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -47,7 +48,7 @@ struct Item {
 };
 
 constexpr int kBins = 12;
-constexpr int kLeafSize = 2;
+constexpr int kLeafSize = 1; // triangle tests are the expensive step of a traversal: one per leaf measured fastest
 
 // Recursive binned-SAH build over items[first, first+count). Node indices are
 // relative to `nodes` (the caller offsets them), children adjacent.
