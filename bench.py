@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--instances", type=int, default=1250, help="instances per GPU")
     ap.add_argument("--subdivisions", type=int, default=5)
     ap.add_argument("--cpu-frames", type=int, default=3, help="CPU-baseline frames (0 = skip)")
+    ap.add_argument("--composite", choices=("auto", "reduce_scatter", "all_reduce"), default="auto",
+                    help="exchange step of the sort-last composite (auto: reduce-scatter on RCCL)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="run the composite / gather collectives even with one rank (rehearsal)")
     args = ap.parse_args()
@@ -105,7 +107,7 @@ def main():
         vis = torch.as_tensor(r.visbuffer_device_array(), device="cuda")  # int64 view of the keys, zero copy
         color = torch.as_tensor(r.color_device_array(), device="cuda")
         assert vis.data_ptr() == r.visbuffer_device_array().__cuda_array_interface__["data"][0]
-        frame = SortLastFrame(r, scene.meshlet_visibility_count, H, rank, world, vis, color)
+        frame = SortLastFrame(r, scene.meshlet_visibility_count, H, rank, world, vis, color, composite=args.composite)
 
     def step():
         if frame is not None:
@@ -172,7 +174,8 @@ def main():
                             f"({tris_per_frame / 1e6:.1f} Mtri submitted per frame), {W}x{H}, lod off; "
                             "stand-in for the Sponza/Bistro 4K configs (assets not shipped)",
                 "instances": args.instances * world, "width": W, "height": H,
-                "parallelism": "single GPU" if world == 1 else f"sort-last x{world}, u64-min all-reduce + row-split shade",
+                "parallelism": "single GPU" if frame is None else
+                               f"sort-last x{world}, u64-min {frame.composite.replace('_', '-')} + row-split shade + RGBA8 all-gather",
             },
             "kernel_ms": {k: round(v, 4) for k, v in kms.items() if v > 0},
             "frame_counters": {k: st[k] for k in ("draws_visible", "meshlets_tested", "meshlets_visible",

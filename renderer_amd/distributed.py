@@ -3,11 +3,16 @@ is RCCL on ROCm).
 
 The reference is single-GPU; this is the one step the path adds.  Every rank holds the whole
 scene, rasterises only its contiguous range of meshlet instances into a full-frame 64-bit
-visibility buffer, and the buffers are composited with one MIN all-reduce: min is associative
-and commutative and the clear value is its identity, so the result is bit-identical to the
-single-GPU buffer.  Keys never set bit 63, hence MIN over int64 (supported by every backend,
-gloo included) equals the unsigned 64-bit min.  Each rank then shades H/N rows and the RGBA8
-rows are all-gathered (half the bytes of gathering keys).
+visibility buffer, and the buffers are composited with one 64-bit MIN reduction: min is
+associative and commutative and the clear value is its identity, so the result is bit-identical
+to the single-GPU buffer.  Keys never set bit 63, hence MIN over int64 (supported by every
+backend, gloo included) equals the unsigned 64-bit min.  Each rank then shades H/N rows and the
+RGBA8 rows are all-gathered (half the bytes of gathering keys).
+
+A rank only ever reads the composited keys of the rows it shades, so on RCCL the reduction runs
+as a reduce-scatter (the first half of a ring all-reduce: (N-1)/N of the buffer per rank instead
+of twice that); the full all-reduce stays available (``composite="all_reduce"``) and is what
+backends without reduce-scatter (gloo) use.
 """
 import torch
 import torch.distributed as dist
@@ -26,6 +31,18 @@ def composite_min(vis_i64):
     """In-place MIN all-reduce of a visibility buffer viewed as int64."""
     assert vis_i64.dtype == torch.int64
     dist.all_reduce(vis_i64, op=dist.ReduceOp.MIN)
+    return vis_i64
+
+
+def composite_min_rows(vis_i64, height, rank, world):
+    """MIN reduce-scatter by row strips: afterwards ``vis_i64`` holds the composited keys in this
+    rank's rows (the rest of the buffer is not meaningful).  Needs equal strips and a backend
+    with reduce-scatter; callers fall back to :func:`composite_min` otherwise."""
+    assert vis_i64.dtype == torch.int64 and height % world == 0
+    flat = vis_i64.view(-1)
+    strip = flat.numel() // world
+    # in place: the output is this rank's slice of the input (RCCL's documented in-place form)
+    dist.reduce_scatter_tensor(flat[rank * strip:(rank + 1) * strip], flat, op=dist.ReduceOp.MIN)
     return vis_i64
 
 
@@ -48,14 +65,22 @@ class SortLastFrame:
     set_shade_rows / render_visbuffer / shade (the HIP ``Renderer`` with device tensors, or the
     CPU oracle with host tensors in the tests)."""
 
-    def __init__(self, renderer, n_instances, height, rank, world, vis_tensor, color_tensor):
-        self.r, self.rank, self.world = renderer, rank, world
+    def __init__(self, renderer, n_instances, height, rank, world, vis_tensor, color_tensor, composite="auto"):
+        self.r, self.rank, self.world, self.height = renderer, rank, world, height
         self.vis, self.color = vis_tensor, color_tensor
+        if composite == "auto":
+            scatter_ok = dist.get_backend() == "nccl" and height % world == 0
+            composite = "reduce_scatter" if scatter_ok else "all_reduce"
+        assert composite in ("reduce_scatter", "all_reduce")
+        self.composite = composite
         renderer.set_partition(*instance_range(n_instances, rank, world))
         renderer.set_shade_rows(*row_range(height, rank, world))
 
     def step(self, camera=None, sun=None):
         self.r.render_visbuffer(camera, sun)
-        composite_min(self.vis)
+        if self.composite == "reduce_scatter":
+            composite_min_rows(self.vis, self.height, self.rank, self.world)
+        else:
+            composite_min(self.vis)
         self.r.shade()
         gather_rows(self.color, self.rank, self.world)
