@@ -28,17 +28,20 @@ def algorithmic_bytes(st, width, height, draws):
     """Bytes each kernel must move per frame, from the frame's own counters: struct sizes are
     the reference's GPU layouts (16 B draw, 64 B transform, 160 B mesh, 32 B meshlet, 32 B cull
     command, 16 B visible-meshlet record, 4 B vertex id + 12 B position, 3 B per triangle,
-    8 B per visibility key, 64 B vertex, 4 B RGBA8)."""
+    8 B per visibility key, 64 B vertex, 4 B RGBA8, 4 B covered-pixel list entry)."""
     px = width * height
+    cov = st["pixels_covered"]
     return {
         "clear": px * 8,
         "draw_cull": draws * (16 + 64 + 160) + st["commands"] * 32,
         "meshlet_cull": st["commands"] * 32 + st["meshlets_tested"] * 32 + st["meshlets_visible"] * 16,
         "raster": st["meshlets_visible"] * (16 + 32) + st["vertices_transformed"] * (4 + 12)
                   + st["triangles_tested"] * 3 + st["fragments"] * 8,
-        # shadow pass: key + 3 positions per covered pixel + 1 B mask; BVH nodes are shared (L2)
-        "shadow": px * 8 + st["pixels_covered"] * (15 + 3 * 12) + px * 1,
-        "shade": px * 8 + px * 1 + st["pixels_covered"] * (15 + 3 * 64) + px * 4,
+        # classification: every key read once, a list entry per covered pixel, the clear colour elsewhere
+        "classify": px * 8 + cov * 4 + (px - cov) * 4,
+        # shadow pass: list entry + key + ids + 3 positions per covered pixel, 1 B result; BVH nodes are shared (L2)
+        "shadow": cov * (4 + 8 + 15 + 3 * 12 + 1),
+        "shade": cov * (4 + 8 + 1 + 15 + 3 * 64 + 4),
     }
 
 
@@ -140,7 +143,7 @@ def main():
         fps = args.steps / elapsed
         kms = st["kernel_ms"]
         ab = algorithmic_bytes(st, W, H, len(scene.mesh_draws))
-        dom = max(("raster", "shade", "shadow", "meshlet_cull", "clear", "draw_cull"), key=lambda k: kms[k])
+        dom = max(("raster", "shade", "shadow", "classify", "meshlet_cull", "clear", "draw_cull"), key=lambda k: kms[k])
         if dom == "raster":
             ab_dom, t_dom = ab["raster"], kms["raster"]
         else:

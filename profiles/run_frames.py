@@ -8,8 +8,13 @@ from renderer_amd import Renderer, RendererConfig, synth  # noqa: E402
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 scene_name = sys.argv[2] if len(sys.argv) > 2 else "field"
 w, h = 3840, 2160
-scene = synth.make_field(1250, 5) if scene_name == "field" else synth.make_atrium(columns=10, spheres=60, sphere_subdiv=5)
-r = Renderer(w, h, RendererConfig(collect_stats=True, time_kernels=True))
+if scene_name == "field":  # exactly bench.py's single-GPU workload
+    scene = synth.make_field(1250, 5, lods=1, with_env=True)
+    conf = RendererConfig(lod_enabled=False, cull_enabled=True, collect_stats=True, time_kernels=True)
+else:
+    scene = synth.make_atrium(columns=10, spheres=60, sphere_subdiv=5)
+    conf = RendererConfig(collect_stats=True, time_kernels=True)
+r = Renderer(w, h, conf)
 r.set_scene(scene)
 for _ in range(frames):
     r.render()
