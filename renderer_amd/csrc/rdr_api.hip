@@ -116,6 +116,7 @@ struct rdr_renderer {
     uint32_t row_lo = 0, row_hi = 0xFFFFFFFFu;
     uint32_t meshlet_visibility_count = 0;
     uint32_t lds_stack_limit = 24;
+    GeometryResidency resident{};
     uint32_t lane_max_pixels = kLaneMaxPixels, mid_max_pixels = kMidMaxPixels;
     uint32_t masked_meshlets = 0; // LOD0 meshlet instances of alpha-masked draws
     rdr_stats stats{};
@@ -341,11 +342,11 @@ FrameView make_frame_view(rdr_renderer* r) {
     fv.stat_slots = r->stat_slots.ptr;
     GridPlan& g = fv.grid;
     g.draw_blocks = std::max(1u, (r->sv.draw_count + 255u) / 256u);
-    g.cull_blocks = std::max(1u, std::min((fv.command_capacity + 15u) / 16u, 1024u));
-    g.raster_blocks = std::max(1u, std::min(fv.visible_capacity, 256u * 32u));
-    g.raster_mask_blocks = std::max(1u, std::min(r->masked_meshlets, 256u * 16u));
+    g.cull_blocks = std::max(1u, std::min((fv.command_capacity + 15u) / 16u, std::max(1u, r->resident.meshlet_cull)));
+    g.raster_blocks = std::max(1u, std::min(fv.visible_capacity, std::max(1u, r->resident.raster)));
+    g.raster_mask_blocks = std::max(1u, std::min(r->masked_meshlets, std::max(1u, r->resident.raster_mask)));
     g.deferred_blocks = fv.tiles_x * fv.tiles_y; // one workgroup per 64x64 tile
-    g.mid_blocks = 2048;
+    g.mid_blocks = std::max(1u, r->resident.mid_raster);
     g.shade_blocks_x = (r->width + 15u) / 16u;
     g.shade_blocks_y = (fv.row_hi - fv.row_lo + 15u) / 16u;
     g.slot_draw = 0;
@@ -401,6 +402,7 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
     if (const char* e = std::getenv("RDR_LANE_MAX_PIXELS")) r->lane_max_pixels = (uint32_t)std::min(4096, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("RDR_MID_MAX_PIXELS")) r->mid_max_pixels = (uint32_t)std::min(4096, std::max(1, std::atoi(e)));
     RDR_HIP(hipSetDevice(r->device));
+    if (rdr_geometry_residency(&r->resident)) return 1;
     RDR_HIP(hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking));
     r->stream = r->own_stream;
     if (r->cfg.time_kernels) {

@@ -121,19 +121,24 @@ __global__ __launch_bounds__(1024) void k_meshlet_cull(SceneView sv, FrameView f
         const uint32_t ci = c0 + wave;
         bool accept = false;
         uint32_t draw_id = 0, first = 0, instance_first = 0, tri_count = 0, count = 0, masked = 0;
+        uint32_t model_index = 0, mesh_vertex_offset = 0, m_vertex_offset = 0, m_triangle_offset = 0, m_counts = 0;
         if (ci < cmd_count) {
             const CullCommand* cp = &fv.commands[__builtin_amdgcn_readfirstlane(ci)];
             draw_id = cp->draw_id; first = cp->meshlet_first; count = cp->count;
             instance_first = cp->instance_first;
             const float max_scale = cp->max_scale;
-            const uint32_t model_index = sv.draws[draw_id].model_index;
-            masked = sv.draws[draw_id].alpha_mode == 1u ? 1u : 0u;
+            const rdr_mesh_draw d = sv.draws[draw_id];
+            model_index = d.model_index;
+            mesh_vertex_offset = sv.meshes[d.mesh_index].vertex_offset;
+            masked = d.alpha_mode == 1u ? 1u : 0u;
             float model[16];
             load_m4(sv.transforms + (size_t)model_index * 16, model);
             accept = lane < count;
             if (accept) {
                 const rdr_meshlet m = sv.meshlets[first + lane];
                 tri_count = m.triangle_count;
+                m_vertex_offset = m.vertex_offset; m_triangle_offset = m.triangle_offset;
+                m_counts = (uint32_t)m.vertex_count | ((uint32_t)m.triangle_count << 16);
                 const vec4 cw = mul_m4(model, mk4(m.center[0], m.center[1], m.center[2], 1.0f));
                 const vec4 cv = mul_m4(u.view, cw);
                 const vec3 cc = mk3(cv.x, cv.y, cv.z);
@@ -170,7 +175,11 @@ __global__ __launch_bounds__(1024) void k_meshlet_cull(SceneView sv, FrameView f
                 v.draw_id = draw_id;
                 v.meshlet_index = first + lane;
                 v.instance = instance_first + lane;
-                v._pad = 0;
+                v.model_index = model_index;
+                v.vertex_offset = m_vertex_offset;
+                v.triangle_offset = m_triangle_offset;
+                v.counts = m_counts;
+                v.mesh_vertex_offset = mesh_vertex_offset;
                 fv.visible[slot] = v;
             }
         }
@@ -439,16 +448,21 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
     const float half_w = (float)fv.width * 0.5f, half_h = (float)fv.height * 0.5f;
 
     uint32_t st_tested = 0, st_raster = 0, st_big = 0, st_frags = 0, st_verts = 0;
+    struct { uint32_t vertex_offset, triangle_offset, vertex_count, triangle_count; } m;
+    VisibleMeshlet vm_next{};
+    if (blockIdx.x < vis_count) vm_next = fv.visible[MASK ? fv.visible_capacity - 1u - blockIdx.x : blockIdx.x];
     for (uint32_t mi = blockIdx.x; mi < vis_count; mi += gridDim.x) {
-        const VisibleMeshlet vm = fv.visible[MASK ? fv.visible_capacity - 1u - mi : mi];
-        const rdr_mesh_draw d = sv.draws[vm.draw_id];
-        const rdr_meshlet m = sv.meshlets[vm.meshlet_index];
-        const uint32_t mesh_vertex_offset = sv.meshes[d.mesh_index].vertex_offset;
+        const VisibleMeshlet vm = vm_next;
+        if (mi + gridDim.x < vis_count) // the next record travels while this meshlet is rasterised
+            vm_next = fv.visible[MASK ? fv.visible_capacity - 1u - (mi + gridDim.x) : mi + gridDim.x];
+        m.vertex_offset = vm.vertex_offset; m.triangle_offset = vm.triangle_offset;
+        m.vertex_count = vm.counts & 0xFFFFu; m.triangle_count = vm.counts >> 16;
+        const uint32_t mesh_vertex_offset = vm.mesh_vertex_offset;
         float model[16];
-        load_m4(sv.transforms + (size_t)d.model_index * 16, model);
+        load_m4(sv.transforms + (size_t)vm.model_index * 16, model);
         AlphaTest at;
         at.enabled = false; at.has_tex = false;
-        if (MASK) at = make_alpha_test(sv, d);
+        if (MASK) at = make_alpha_test(sv, sv.draws[vm.draw_id]);
         const bool cull_front = !MASK;
 
         __syncthreads(); // previous meshlet's readers are done
@@ -1034,6 +1048,23 @@ __global__ __launch_bounds__(256) void k_resolve(SceneView sv, FrameView fv, uin
 }
 
 } // namespace
+
+// Workgroups of each persistent kernel that are resident at once on the current device:
+// their grids are sized to exactly one resident round, so no workgroup waits for a slot.
+int rdr_geometry_residency(GeometryResidency* out) {
+    int device = 0, cus = 0, n = 0;
+    RDR_HIP(hipGetDevice(&device));
+    RDR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_meshlet_cull, 1024, 0));
+    out->meshlet_cull = (uint32_t)(n * cus);
+    RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_raster<false>, 64, 0));
+    out->raster = (uint32_t)(n * cus);
+    RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_raster<true>, 64, 0));
+    out->raster_mask = (uint32_t)(n * cus);
+    RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mid_raster, 256, 0));
+    out->mid_raster = (uint32_t)(n * cus);
+    return 0;
+}
 
 int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev) {
     const size_t npx = (size_t)fv.width * fv.height;

@@ -41,12 +41,19 @@ struct CullCommand {
 static_assert(sizeof(CullCommand) == 32, "CullCommand must be 32 bytes");
 
 // A meshlet that survived culling, input of the rasteriser.
+// Carries what the rasteriser needs to start fetching vertices at once (no draw ->
+// mesh -> meshlet pointer chase per meshlet).
 struct VisibleMeshlet {
     uint32_t draw_id;
     uint32_t meshlet_index;
     uint32_t instance;
-    uint32_t _pad;
+    uint32_t model_index;        // of the draw
+    uint32_t vertex_offset;      // of the meshlet, into meshlet_vertices
+    uint32_t triangle_offset;    // of the meshlet, into meshlet_triangles
+    uint32_t counts;             // vertex_count | triangle_count << 16
+    uint32_t mesh_vertex_offset; // of the mesh, added to every meshlet vertex index
 };
+static_assert(sizeof(VisibleMeshlet) == 32, "VisibleMeshlet layout");
 
 // A triangle the per-meshlet rasteriser hands to the clip / tile path: its three
 // clip-space vertices (position + both uv sets) and its identity.
@@ -237,6 +244,10 @@ void rdr_build_tlas(const rdr_scene_desc& s, const float* transforms, HostBvh& i
 
 // ---- kernel launchers (rdr_geometry.hip / rdr_shade.hip) ---------------------
 int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev);
+struct GeometryResidency {
+    uint32_t meshlet_cull, raster, raster_mask, mid_raster; // resident workgroups on the whole device
+};
+int rdr_geometry_residency(GeometryResidency* out);
 int rdr_launch_shadow(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev); // classify + shadow rays
 int rdr_launch_shade(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev);  // the above, then k_shade
 int rdr_launch_resolve(const SceneView& sv, const FrameView& fv, uint32_t* out_xy, hipStream_t stream);
