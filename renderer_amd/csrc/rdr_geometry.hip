@@ -261,9 +261,10 @@ RDR_DEV void emit_fragment(const FrameView& fv, int px, int py, float z, uint32_
     const unsigned long long key =
         ((unsigned long long)(0x7FFFFFFFu - __float_as_uint(z)) << 32) | (unsigned long long)id;
     unsigned long long* p = &fv.vis[(size_t)py * fv.width + px];
-    // cheap pre-test: most fragments of an already covered pixel lose
-    if (key < __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        __hip_atomic_fetch_min(p, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // The result is not used: the atomic is issued and forgotten, so a lane that produces
+    // several fragments never waits for a round trip to the L2 (a pre-test load would cost
+    // one per fragment).
+    __hip_atomic_fetch_min(p, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Perspective-correct uv at the sample with edge values (e0, e1, e2).
@@ -449,12 +450,20 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
 
     uint32_t st_tested = 0, st_raster = 0, st_big = 0, st_frags = 0, st_verts = 0;
     struct { uint32_t vertex_offset, triangle_offset, vertex_count, triangle_count; } m;
+    // Software pipeline over the wave's meshlets: the next record is requested a whole
+    // meshlet ahead and the next meshlet's vertex indices before this one's triangles, so
+    // that one dependent fetch (the positions) is what a meshlet still waits for.
     VisibleMeshlet vm_next{};
-    if (blockIdx.x < vis_count) vm_next = fv.visible[MASK ? fv.visible_capacity - 1u - blockIdx.x : blockIdx.x];
+    uint32_t vi_next = 0;
+    if (blockIdx.x < vis_count) {
+        vm_next = fv.visible[MASK ? fv.visible_capacity - 1u - blockIdx.x : blockIdx.x];
+        if (lane < (vm_next.counts & 0xFFFFu)) vi_next = sv.meshlet_vertices[vm_next.vertex_offset + lane] + vm_next.mesh_vertex_offset;
+    }
     for (uint32_t mi = blockIdx.x; mi < vis_count; mi += gridDim.x) {
         const VisibleMeshlet vm = vm_next;
-        if (mi + gridDim.x < vis_count) // the next record travels while this meshlet is rasterised
-            vm_next = fv.visible[MASK ? fv.visible_capacity - 1u - (mi + gridDim.x) : mi + gridDim.x];
+        const uint32_t vi = vi_next;
+        const bool has_next = mi + gridDim.x < vis_count;
+        if (has_next) vm_next = fv.visible[MASK ? fv.visible_capacity - 1u - (mi + gridDim.x) : mi + gridDim.x];
         m.vertex_offset = vm.vertex_offset; m.triangle_offset = vm.triangle_offset;
         m.vertex_count = vm.counts & 0xFFFFu; m.triangle_count = vm.counts >> 16;
         const uint32_t mesh_vertex_offset = vm.mesh_vertex_offset;
@@ -465,10 +474,15 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
         if (MASK) at = make_alpha_test(sv, sv.draws[vm.draw_id]);
         const bool cull_front = !MASK;
 
+        uint32_t first_tri = 0; // the lane's first triangle's vertex bytes, fetched ahead of the vertex phase
+        if (lane < m.triangle_count) {
+            const uint8_t* tp = sv.meshlet_triangles + m.triangle_offset + lane * 3;
+            first_tri = (uint32_t)tp[0] | ((uint32_t)tp[1] << 8) | ((uint32_t)tp[2] << 16);
+        }
+
         __syncthreads(); // previous meshlet's readers are done
         if (lane < m.vertex_count) {
             st_verts++;
-            const uint32_t vi = sv.meshlet_vertices[m.vertex_offset + lane] + mesh_vertex_offset;
             const vec4 world = mul_m4(model, mk4(sv.pos_x[vi], sv.pos_y[vi], sv.pos_z[vi], 1.0f));
             const vec4 clip = mul_m4(u.view_proj, world);
             lds.cx[lane] = clip.x; lds.cy[lane] = clip.y; lds.cz[lane] = clip.z; lds.cw[lane] = clip.w;
@@ -482,6 +496,8 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
             lds.clip[lane] = nc ? 1u : 0u;
         }
         __syncthreads();
+        if (has_next && lane < (vm_next.counts & 0xFFFFu)) // in flight during the triangle phase
+            vi_next = sv.meshlet_vertices[vm_next.vertex_offset + lane] + vm_next.mesh_vertex_offset;
 
         for (uint32_t t0 = 0; t0 < m.triangle_count; t0 += 64) {
             const uint32_t ti = t0 + lane;
@@ -509,8 +525,12 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
                 }
             };
             if (ti < m.triangle_count) {
-                const uint8_t* tp = sv.meshlet_triangles + m.triangle_offset + ti * 3;
-                ia = tp[0]; ib = tp[1]; ic = tp[2];
+                uint32_t tri_bytes = first_tri;
+                if (t0) {
+                    const uint8_t* tp = sv.meshlet_triangles + m.triangle_offset + ti * 3;
+                    tri_bytes = (uint32_t)tp[0] | ((uint32_t)tp[1] << 8) | ((uint32_t)tp[2] << 16);
+                }
+                ia = tri_bytes & 255u; ib = (tri_bytes >> 8) & 255u; ic = tri_bytes >> 16;
                 st_tested++;
                 const float ax = lds.sx[ia], ay = lds.sy[ia], bx = lds.sx[ib], by = lds.sy[ib];
                 const float cx = lds.sx[ic], cy = lds.sy[ic];
