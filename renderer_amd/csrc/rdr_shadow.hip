@@ -166,7 +166,9 @@ RDR_DEV bool shadow_any_hit(const SceneView& sv, uint32_t own_instance, vec3 o, 
                 st.push_if(h & (cur != kBvhNone), cur);
                 cur = h ? code[i] : cur;
             }
-        } else if (cur != kBvhNone) {
+        }
+        // not "else": a leaf that the node above just selected is tested in the same iteration
+        if ((cur & kBvhLeaf) && cur != kBvhNone) {
             const uint32_t count = (cur >> 24) & 127u, first = cur & 0xFFFFFFu;
             cur = kBvhNone;
             if (floor >= 0) {
