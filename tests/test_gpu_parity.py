@@ -100,6 +100,22 @@ def test_alpha_masked_field(oracle):
     check_color(o, g)
 
 
+@pytest.mark.parametrize("lane_max,mid_max", [(1, 1), (1, 4096), (4096, 4096), (16, 64)])
+def test_raster_routing_is_result_neutral(oracle, monkeypatch, lane_max, mid_max):
+    """Which of the three rasterisers (per-lane scan, wave per triangle, tile bins) takes a
+    triangle is a performance choice: every routing yields the oracle's buffer, opaque and
+    alpha-masked, close up (large triangles) and from afar."""
+    monkeypatch.setenv("RDR_LANE_MAX_PIXELS", str(lane_max))
+    monkeypatch.setenv("RDR_MID_MAX_PIXELS", str(mid_max))
+    sc = synth.make_field(40, 2, alpha_fraction=0.5)
+    sc.camera = Camera((0.0, 2.0, -8.0), (0.0, 0.2, -1.0))
+    o, ovis, g = both(oracle, sc, 480, 270, shade=False)
+    check_vis(o, ovis, g)
+    sc = synth.make_atrium()
+    o, ovis, g = both(oracle, sc, 256, 144, shade=False)
+    check_vis(o, ovis, g)
+
+
 def test_shadow_deep_stack_path(oracle, monkeypatch):
     """Rays whose traversal overflows the LDS stack are re-traced with the deep stack."""
     monkeypatch.setenv("RDR_DEBUG_STACK_LIMIT", "3")
