@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=3, help="CPU-baseline frames (0 = skip)")
     ap.add_argument("--composite", choices=("auto", "reduce_scatter", "all_reduce"), default="auto",
                     help="exchange step of the sort-last composite (auto: reduce-scatter on RCCL)")
+    ap.add_argument("--frames-in-flight", type=int, default=int(os.environ.get("RDR_FRAMES_IN_FLIGHT", "2")),
+                    help="multi-GPU only: renderers taking turns so that one frame's exchange overlaps the next frame's raster")
     ap.add_argument("--force-collectives", action="store_true",
                     help="run the composite / gather collectives even with one rank (rehearsal)")
     args = ap.parse_args()
@@ -99,28 +101,30 @@ def main():
     scene = synth.make_field(args.instances * world, args.subdivisions, lods=1, with_env=True)
     tris_per_frame = scene.triangle_count()
     conf = RendererConfig(lod_enabled=False, cull_enabled=True, collect_stats=True, time_kernels=True)
-    r = Renderer(W, H, conf, device=local_rank)
-    r.set_scene(scene)
-    stream = torch.cuda.current_stream()
-    r.set_stream(stream.cuda_stream)  # kernels run on torch's stream: ordered with the collectives
+    def make_renderer():
+        rr = Renderer(W, H, conf, device=local_rank)
+        rr.set_scene(scene)
+        return rr
 
     frame = None
     if multi:
-        from renderer_amd.distributed import SortLastFrame
-        vis = torch.as_tensor(r.visbuffer_device_array(), device="cuda")  # int64 view of the keys, zero copy
-        color = torch.as_tensor(r.color_device_array(), device="cuda")
-        assert vis.data_ptr() == r.visbuffer_device_array().__cuda_array_interface__["data"][0]
-        frame = SortLastFrame(r, scene.meshlet_visibility_count, H, rank, world, vis, color, composite=args.composite)
+        from renderer_amd.distributed import SortLastPipeline
+        frame = SortLastPipeline(make_renderer, scene.meshlet_visibility_count, H, rank, world,
+                                 depth=args.frames_in_flight, composite=args.composite)
+        r = frame.renderers()[0]
+    else:
+        r = make_renderer()
+        r.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def step():
         if frame is not None:
-            frame.step()  # raster own share -> u64-min all-reduce -> shade own rows -> all-gather
+            frame.step()  # raster own share -> u64-min exchange -> shade own rows -> all-gather, on the slot's stream
         else:
             r.render()
 
     for _ in range(args.warmup):
         step()
-    r.sync()
+    torch.cuda.synchronize()
     r.stats()  # drop the warm-up frames from the kernel timers
     if multi:
         dist.barrier()
@@ -178,7 +182,8 @@ def main():
                             "stand-in for the Sponza/Bistro 4K configs (assets not shipped)",
                 "instances": args.instances * world, "width": W, "height": H,
                 "parallelism": "single GPU" if frame is None else
-                               f"sort-last x{world}, u64-min {frame.composite.replace('_', '-')} + row-split shade + RGBA8 all-gather",
+                               f"sort-last x{world}, u64-min {frame.composite.replace('_', '-')} + row-split shade + RGBA8 all-gather, "
+                               f"{len(frame.slots)} frames in flight",
             },
             "kernel_ms": {k: round(v, 4) for k, v in kms.items() if v > 0},
             "frame_counters": {k: st[k] for k in ("draws_visible", "meshlets_tested", "meshlets_visible",
@@ -197,7 +202,10 @@ def main():
                                    "sample": f"{args.cpu_frames} full frames of the same workload "
                                              "(CPU restatement of the reference path, OpenMP; not lavapipe)"}
         print(json.dumps(out), flush=True)
-    r.close()
+    if frame is not None:
+        frame.close()
+    else:
+        r.close()
     if multi:
         dist.destroy_process_group()
 

@@ -84,3 +84,42 @@ class SortLastFrame:
             composite_min(self.vis)
         self.r.shade()
         gather_rows(self.color, self.rank, self.world)
+
+
+class SortLastPipeline:
+    """Several frames in flight on one rank: ``depth`` renderers (each with its own buffers and
+    its own HIP stream) take turns, so that frame i+1 is rasterised while frame i's keys and
+    colour rows are on the links.  The host never waits inside :meth:`step`; every rank issues
+    the same collectives in the same order, and a slot's stream orders its reuse.
+
+    ``make_renderer`` builds a HIP ``Renderer`` with the scene already set."""
+
+    def __init__(self, make_renderer, n_instances, height, rank, world, depth=2, composite="auto"):
+        self.slots = []
+        for _ in range(max(1, depth)):
+            r = make_renderer()
+            stream = torch.cuda.Stream()
+            r.set_stream(stream.cuda_stream)
+            vis = torch.as_tensor(r.visbuffer_device_array(), device="cuda")
+            color = torch.as_tensor(r.color_device_array(), device="cuda")
+            self.slots.append((SortLastFrame(r, n_instances, height, rank, world, vis, color, composite), stream))
+        self.composite = self.slots[0][0].composite
+        self.issued = 0
+
+    def step(self, camera=None, sun=None):
+        """Issue one frame; returns its slot's ``SortLastFrame`` (``.color`` is valid once
+        ``.stream`` / the device has been synchronised)."""
+        frame, stream = self.slots[self.issued % len(self.slots)]
+        self.issued += 1
+        with torch.cuda.stream(stream):
+            frame.step(camera, sun)
+        frame.stream = stream
+        return frame
+
+    def renderers(self):
+        return [f.r for f, _ in self.slots]
+
+    def close(self):
+        torch.cuda.synchronize()
+        for f, _ in self.slots:
+            f.r.close()
