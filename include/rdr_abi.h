@@ -174,7 +174,7 @@ typedef struct rdr_cubemap_desc {
 /* scenery/src/scene.rs:27-33 (EnvMap), bound at renderer/src/renderer/pass.rs:539-558 */
 typedef struct rdr_env_desc {
     rdr_image_desc brdf_lut;
-    rdr_cubemap_desc skybox; /* accepted, not sampled by this path */
+    rdr_cubemap_desc skybox; /* background, sampled when rdr_config.skybox = 1 */
     rdr_cubemap_desc lambertian;
     rdr_cubemap_desc ggx;
     rdr_cubemap_desc charlie;
@@ -214,6 +214,8 @@ typedef struct rdr_config {
     uint32_t cull_enabled;   /* accepted; occlusion culling is result-neutral and not run */
     uint32_t collect_stats;  /* 1: count triangles/fragments per frame (small cost) */
     uint32_t time_kernels;   /* 1: bracket each kernel with events for rdr_get_stats */
+    uint32_t skybox;         /* 1: pixels with no geometry show env.skybox (SkyBoxPass,
+                              * renderer/src/renderer/pass.rs:397-445); 0: they stay (0,0,0,0) */
 } rdr_config;
 
 /* Packed visibility-buffer key written by the rasteriser with a 64-bit

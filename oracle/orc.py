@@ -35,6 +35,7 @@ def lib():
         L.orc_resolve.argtypes = [C.POINTER(abi.SceneDesc), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_shade.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.Ubo), C.c_void_p, C.c_void_p, C.c_uint32,
                                 C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_skybox.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.Ubo), C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_num_threads.restype = C.c_int
         _LIB = L
     return _LIB
@@ -58,6 +59,7 @@ class OracleRenderer:
         self.width, self.height = width, height
         self.lod_enabled = bool(config.lod_enabled) if config else False
         self.cull_enabled = bool(config.cull_enabled) if config else True
+        self.skybox = bool(getattr(config, "skybox", False)) if config else False
         self.part = (0, 0xFFFFFFFF)
         self.stats = abi.Stats()
 
@@ -88,6 +90,9 @@ class OracleRenderer:
         rc = lib().orc_shade(C.byref(self.desc), C.byref(self.ubo), vis.ctypes.data, self.draw_lod.ctypes.data,
                              rows[0], rows[1], out.ctypes.data, lin.ctypes.data if want_linear else None)
         assert rc == 0
+        if self.skybox:
+            rc = lib().orc_skybox(C.byref(self.desc), C.byref(self.ubo), vis.ctypes.data, rows[0], rows[1], out.ctypes.data)
+            assert rc == 0
         return (out, lin) if want_linear else out
 
     def render(self, camera=None, sun=None):

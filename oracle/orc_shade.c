@@ -679,3 +679,39 @@ int orc_shade(const rdr_scene_desc* s, const rdr_ubo* u, const uint64_t* vis, co
     shadow_scene_free(&ss);
     return 0;
 }
+
+/* Skybox pass on the pixels no geometry covers (renderer/src/renderer/pass.rs:397-445).  The
+ * reference draws a cube of half-size 10 000 centred on the camera (cubemap.vert.glsl:11-46)
+ * with the depth test GREATER against the frame's depth image (lava/src/pipelines.rs:189-191):
+ * it survives exactly where the depth is still the clear value 0, and the interpolated `dir`
+ * (cubemap.vert.glsl:46) is the pixel's view ray up to a positive scale, so
+ * texture(cubemap, dir) (cubemap.frag.glsl:11) is the cubemap seen along that ray.  The
+ * implicit LOD is taken as 0, like the other implicit-LOD fetches of this restatement.  The
+ * colour goes through the swapchain's sRGB encode, alpha is stored as is. */
+int orc_skybox(const rdr_scene_desc* s, const rdr_ubo* u, const uint64_t* vis, uint32_t row_lo, uint32_t row_hi,
+               uint8_t* out_rgba8) {
+    int W = (int)u->screen_width, H = (int)u->screen_height;
+    if (row_hi > (uint32_t)H) row_hi = (uint32_t)H;
+    if (!s->env || !s->env->skybox.data || s->env->skybox.mip_count == 0) return 0;
+    const rdr_cubemap_desc* cm = &s->env->skybox;
+#pragma omp parallel for schedule(static)
+    for (int iy = (int)row_lo; iy < (int)row_hi; ++iy) {
+        for (int ix = 0; ix < W; ++ix) {
+            size_t pi = (size_t)iy * W + ix;
+            if (vis[pi] != RDR_VIS_CLEAR) continue;
+            float nx = (((float)ix + 0.5f) / (float)W) * 2.0f - 1.0f;
+            float ny = (1.0f - ((float)iy + 0.5f) / (float)H) * 2.0f - 1.0f;
+            /* view-space ray (x/z, y/z, 1) from the projection's scales, then the view rotation transposed */
+            float vx = nx / u->proj[0], vy = ny / u->proj[5];
+            v3 d;
+            d.x = (u->view[0] * vx + u->view[1] * vy) + u->view[2];
+            d.y = (u->view[4] * vx + u->view[5] * vy) + u->view[6];
+            d.z = (u->view[8] * vx + u->view[9] * vy) + u->view[10];
+            v4 c = orc_cube_sample_lod(cm, d, 0.0f);
+            uint8_t* o8 = out_rgba8 + pi * 4;
+            o8[0] = srgb_encode(c.x); o8[1] = srgb_encode(c.y); o8[2] = srgb_encode(c.z);
+            o8[3] = (uint8_t)floorf(clampf(c.w, 0.0f, 1.0f) * 255.0f + 0.5f);
+        }
+    }
+    return 0;
+}

@@ -34,6 +34,11 @@ int orc_shade(const rdr_scene_desc* scene, const rdr_ubo* ubo, const uint64_t* v
               const uint8_t* draw_lod, uint32_t row_lo, uint32_t row_hi, uint8_t* out_rgba8,
               float* out_linear);
 
+/* Skybox pass: fills the pixels of rows [row_lo, row_hi) whose key is the clear
+ * value from env.skybox (no-op without one).  Run after orc_shade. */
+int orc_skybox(const rdr_scene_desc* scene, const rdr_ubo* ubo, const uint64_t* vis,
+               uint32_t row_lo, uint32_t row_hi, uint8_t* out_rgba8);
+
 int orc_num_threads(void);
 
 #ifdef __cplusplus

@@ -167,7 +167,7 @@ class SceneDesc(C.Structure):
 
 class Config(C.Structure):
     _fields_ = [("lod_enabled", C.c_uint32), ("cull_enabled", C.c_uint32),
-                ("collect_stats", C.c_uint32), ("time_kernels", C.c_uint32)]
+                ("collect_stats", C.c_uint32), ("time_kernels", C.c_uint32), ("skybox", C.c_uint32)]
 
 
 STAT_KERNELS = 8

@@ -334,6 +334,7 @@ FrameView make_frame_view(rdr_renderer* r) {
     fv.mid = r->mid.ptr;
     fv.mid_mask = r->mid_mask.ptr;
     fv.mid_capacity = (uint32_t)r->mid.count;
+    fv.skybox = (r->cfg.skybox && r->sv.skybox.mip_count) ? 1u : 0u;
     fv.lane_max_pixels = r->lane_max_pixels;
     fv.mid_max_pixels = r->mid_max_pixels;
     fv.bin_capacity = (uint32_t)r->bin_entries.count;
@@ -535,6 +536,7 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
         if (pack_cubemap(tp, s.env ? &s.env->lambertian : nullptr, &r->sv.lambertian)) return 1;
         if (pack_cubemap(tp, s.env ? &s.env->ggx : nullptr, &r->sv.ggx)) return 1;
         if (pack_cubemap(tp, s.env ? &s.env->charlie : nullptr, &r->sv.charlie)) return 1;
+        if (pack_cubemap(tp, s.env ? &s.env->skybox : nullptr, &r->sv.skybox)) return 1;
         if (r->images.upload(imgs.data(), imgs.size())) return 1;
         if (r->texels.upload(tp.blob.data(), tp.blob.size())) return 1;
     }

@@ -180,7 +180,7 @@ struct SceneView {
     const GpuInstance* instances;
     // environment
     GpuImage brdf_lut;
-    GpuCubemap lambertian, ggx, charlie;
+    GpuCubemap lambertian, ggx, charlie, skybox;
 };
 
 // Launch geometry of one frame and where each kernel's workgroups put their statistics.
@@ -220,6 +220,7 @@ struct FrameView {
     // queued for k_mid_raster (a wave per triangle, 8x8 pixels per step), beyond that (and
     // for larger or clipped triangles) it goes to the tile path.
     uint32_t lane_max_pixels, mid_max_pixels;
+    uint32_t skybox; // 1: uncovered pixels get the skybox (k_skybox) instead of the clear colour
     uint32_t lds_stack_limit; // entries of the LDS traversal stack in use (<= 24; lowered only by tests)
     // Per-workgroup statistics: every workgroup stores its partial counts in its own
     // slot with plain stores (no contended atomics); the host sums the slots on request.

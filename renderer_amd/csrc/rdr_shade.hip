@@ -304,6 +304,29 @@ __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv) {
         srgb_encode(c.x) | (srgb_encode(c.y) << 8) | (srgb_encode(c.z) << 16) | (255u << 24);
 }
 
+// Skybox pass (assets/shaders/cubemap.vert.glsl:41-47, cubemap.frag.glsl:9-12,
+// renderer/src/renderer/pass.rs:397-445): a camera-centred cube drawn with the depth test
+// GREATER survives exactly on the pixels still at the clear depth, and its interpolated
+// direction is the pixel's view ray, so every uncovered pixel shows the cubemap along its
+// ray (implicit LOD taken as 0), sRGB-encoded by the store; alpha is stored as is.
+__global__ __launch_bounds__(256) void k_skybox(SceneView sv, FrameView fv) {
+    const uint32_t ix = blockIdx.x * 64u + (threadIdx.x & 63u);
+    const uint32_t iy = fv.row_lo + blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (ix >= fv.width || iy >= fv.row_hi) return;
+    const size_t pi = (size_t)iy * fv.width + ix;
+    if (fv.vis[pi] != RDR_VIS_CLEAR) return;
+    const rdr_ubo& u = fv.ubo;
+    const float nx = (((float)ix + 0.5f) / (float)fv.width) * 2.0f - 1.0f;
+    const float ny = (1.0f - ((float)iy + 0.5f) / (float)fv.height) * 2.0f - 1.0f;
+    // view-space ray (x/z, y/z, 1) from the projection's scales, then the view rotation transposed
+    const float vx = nx / u.proj[0], vy = ny / u.proj[5];
+    const vec3 d = mk3((u.view[0] * vx + u.view[1] * vy) + u.view[2], (u.view[4] * vx + u.view[5] * vy) + u.view[6],
+                       (u.view[8] * vx + u.view[9] * vy) + u.view[10]);
+    const vec4 c = cube_sample_lod(sv.skybox, sv.texels, d, 0.0f);
+    const uint32_t a = (uint32_t)floorf(clampf(c.w, 0.0f, 1.0f) * 255.0f + 0.5f);
+    reinterpret_cast<uint32_t*>(fv.color)[pi] = srgb_encode(c.x) | (srgb_encode(c.y) << 8) | (srgb_encode(c.z) << 16) | (a << 24);
+}
+
 } // namespace
 
 int rdr_launch_shade(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev) {
@@ -311,6 +334,8 @@ int rdr_launch_shade(const SceneView& sv, const FrameView& fv, hipStream_t strea
     if (rdr_launch_shadow(sv, fv, stream, ev)) return 1;
     const uint32_t list_blocks = (uint32_t)(((size_t)(fv.row_hi - fv.row_lo) * fv.width + 255u) / 256u);
     hipLaunchKernelGGL(k_shade, dim3(list_blocks), dim3(256), 0, stream, sv, fv);
+    if (fv.skybox)
+        hipLaunchKernelGGL(k_skybox, dim3((fv.width + 63u) / 64u, (fv.row_hi - fv.row_lo + 3u) / 4u), dim3(256), 0, stream, sv, fv);
     if (ev) RDR_HIP(hipEventRecord(ev[9], stream));
     RDR_HIP(hipGetLastError());
     return 0;

@@ -95,7 +95,8 @@ class Renderer:
         self._h = C.c_void_p()
         self.width, self.height = int(width), int(height)
         cfg = abi.Config(int(config.lod_enabled) if config else 0, int(config.cull_enabled) if config else 1,
-                         int(config.collect_stats) if config else 1, int(config.time_kernels) if config else 0)
+                         int(config.collect_stats) if config else 1, int(config.time_kernels) if config else 0,
+                         int(getattr(config, "skybox", False)) if config else 0)
         dev = (C.c_int * 1)(int(device))
         self._check(self._L.rdr_create(C.byref(cfg), self.width, self.height, dev, 1, C.byref(self._h)))
         self.scene = None

@@ -31,6 +31,7 @@ class RendererConfig:
     cull_enabled: bool = True
     collect_stats: bool = True
     time_kernels: bool = False
+    skybox: bool = False  # run the skybox pass (renderer/src/renderer/pass.rs:397-445) on uncovered pixels
 
 
 @dataclass

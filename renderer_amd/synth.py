@@ -278,6 +278,7 @@ def default_env(sun=(-0.23623444, 0.9302103, 0.2808959), size=32, lut_size=64):
         lambertian=sky_cubemap(max(8, size // 2), 1, s, 1.0, 1.0),
         ggx=sky_cubemap(size, int(math.log2(size)) + 1, s, 0.0, 1.0),
         charlie=sky_cubemap(size, int(math.log2(size)) + 1, s, 0.3, 1.0),
+        skybox=sky_cubemap(size * 2, 1, s, 0.0, 1.0),
     )
 
 
