@@ -59,6 +59,42 @@ def cpu_baseline(scene, width, height, frames):
     return dt, orc.num_threads()
 
 
+def secondary_series(W, H, frames, instances, subdivisions):
+    """Shorter runs of the other workloads the measurement plan names, after the timed region."""
+    import torch
+    from renderer_amd import Renderer, RendererConfig, synth
+    cases = [
+        ("field, lod on (3 levels)", lambda: synth.make_field(instances, subdivisions, lods=3, with_env=True),
+         RendererConfig(lod_enabled=True, collect_stats=True)),
+        ("field, 50% of draws alpha-masked (checkerboard albedo, cutoff 0.5)",
+         lambda: synth.make_field(instances, subdivisions, lods=1, alpha_fraction=0.5, with_env=True),
+         RendererConfig(lod_enabled=False, collect_stats=True)),
+        ("atrium (interior stand-in for Sponza: every pixel covered, textured, large clipped triangles), skybox on",
+         lambda: synth.make_atrium(columns=10, spheres=60, sphere_subdiv=5), RendererConfig(collect_stats=True, skybox=True)),
+    ]
+    out = []
+    for name, make, conf in cases:
+        scene = make()
+        r = Renderer(W, H, conf)
+        r.set_scene(scene)
+        for _ in range(5):
+            r.render()
+        r.sync()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            r.render()
+        r.sync()
+        dt = (time.perf_counter() - t0) / frames
+        st = r.stats()
+        out.append({"workload": name, "frames_per_s": 1.0 / dt, "ms_per_frame": dt * 1e3,
+                    "Mtri_per_s_submitted": st["triangles_submitted"] / dt / 1e6,
+                    "Mtri_per_s_rasterised": st["triangles_rasterised"] / dt / 1e6,
+                    "fragments": st["fragments"], "pixels_covered": st["pixels_covered"]})
+        r.close()
+    torch.cuda.synchronize()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +105,8 @@ def main():
     ap.add_argument("--instances", type=int, default=1250, help="instances per GPU")
     ap.add_argument("--subdivisions", type=int, default=5)
     ap.add_argument("--cpu-frames", type=int, default=3, help="CPU-baseline frames (0 = skip)")
+    ap.add_argument("--secondary-frames", type=int, default=50,
+                    help="single GPU only: frames for the secondary series (LOD on, alpha-masked, atrium); 0 = skip")
     ap.add_argument("--composite", choices=("auto", "reduce_scatter", "all_reduce"), default="auto",
                     help="exchange step of the sort-last composite (auto: reduce-scatter on RCCL)")
     ap.add_argument("--frames-in-flight", type=int, default=int(os.environ.get("RDR_FRAMES_IN_FLIGHT", "2")),
@@ -195,6 +233,13 @@ def main():
                          "frame_algorithmic_bytes": sum(ab.values()),
                          "frame_frac": sum(ab.values()) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+        raster_s = (kms["raster"] + kms["big_raster"]) * 1e-3
+        if raster_s > 0:  # the rasteriser's own roofline is the L2 atomic rate (per-lane and per-wave scans issue one per fragment)
+            out["raster_atomics"] = {"fragments": st["fragments"], "per_s": st["fragments"] / raster_s,
+                                     "bytes_per_s": st["fragments"] * 8 / raster_s,
+                                     "note": "64-bit atomicMin issued per fragment by k_raster / k_mid_raster; the tile path merges without atomics"}
+        if world == 1 and frame is None and args.secondary_frames > 0:
+            out["secondary"] = secondary_series(W, H, args.secondary_frames, args.instances, args.subdivisions)
         if world == 1 and args.cpu_frames > 0:
             dt, threads = cpu_baseline(scene, W, H, args.cpu_frames)
             out["cpu_baseline"] = {"value": tris_per_frame / dt / 1e6, "unit": "Mtri/s", "cores": threads,
