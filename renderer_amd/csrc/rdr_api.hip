@@ -97,6 +97,10 @@ struct rdr_renderer {
     DeviceBuffer<float> transforms;
     DeviceBuffer<uint32_t> instance_draw;
     DeviceBuffer<uint8_t> draw_lod;
+    DeviceBuffer<uint8_t> draw_visible;
+    DeviceBuffer<uint32_t> meshlet_bits;
+    DeviceBuffer<uint32_t> pyramid;
+    bool occlusion = false; // cfg.cull_enabled, unless RDR_OCCLUSION=0
     DeviceBuffer<GpuImage> images;
     DeviceBuffer<uint8_t> texels;
     DeviceBuffer<BvhWide> bvh_dev; // bottom levels followed by room for the top level
@@ -335,6 +339,22 @@ FrameView make_frame_view(rdr_renderer* r) {
     fv.mid_mask = r->mid_mask.ptr;
     fv.mid_capacity = (uint32_t)r->mid.count;
     fv.skybox = (r->cfg.skybox && r->sv.skybox.mip_count) ? 1u : 0u;
+    fv.occlusion = r->occlusion ? 1u : 0u;
+    fv.draw_visible = r->draw_visible.ptr;
+    fv.meshlet_bits = r->meshlet_bits.ptr;
+    fv.pyramid = r->pyramid.ptr;
+    {
+        uint32_t off = 0, l = 0;
+        for (;; ++l) {
+            const uint32_t step = 2u << l; // pixels per texel side at level l
+            fv.pyr_w[l] = (r->width + step - 1u) / step;
+            fv.pyr_h[l] = (r->height + step - 1u) / step;
+            fv.pyr_offset[l] = off;
+            off += fv.pyr_w[l] * fv.pyr_h[l];
+            if ((fv.pyr_w[l] == 1u && fv.pyr_h[l] == 1u) || l == 15u) break;
+        }
+        fv.pyr_levels = l + 1u;
+    }
     fv.lane_max_pixels = r->lane_max_pixels;
     fv.mid_max_pixels = r->mid_max_pixels;
     fv.bin_capacity = (uint32_t)r->bin_entries.count;
@@ -397,6 +417,8 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
     std::unique_ptr<rdr_renderer> r(new rdr_renderer());
     if (cfg) r->cfg = *cfg;
     r->width = width; r->height = height; r->device = hip_devices[0];
+    r->occlusion = r->cfg.cull_enabled != 0;
+    if (const char* e = std::getenv("RDR_OCCLUSION")) r->occlusion = r->occlusion && std::atoi(e) != 0; // tuning hook
     if (const char* e = std::getenv("RDR_DEBUG_STACK_LIMIT")) // test hook: force the deep-stack shadow path
         r->lds_stack_limit = (uint32_t)std::min(24, std::max(1, std::atoi(e)));
     // tuning hooks: bounding-box pixel counts at which k_raster hands a triangle to k_mid_raster / the tile path
@@ -413,6 +435,8 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
     const size_t npx = (size_t)width * height;
     if (r->vis.alloc(npx) || r->color.alloc(npx * 4) || r->counters.alloc(1) || r->shadow.alloc(npx) ||
         r->pixel_list.alloc(npx)) return 1;
+    // depth pyramid: W/2 x H/2 and its mips, a little over a third of a pixel count
+    if (r->pyramid.alloc(npx / 2 + width + height + 64)) return 1; // sum over levels <= W*H/3 + W + H + levels
     {
         const size_t n_tiles = (size_t)((width + 63) / 64) * ((height + 63) / 64);
         if (r->tile_count.alloc(n_tiles) || r->tile_offset.alloc(n_tiles) || r->tile_cursor.alloc(n_tiles)) return 1;
@@ -480,7 +504,11 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
     if (r->draws.upload(s.mesh_draws, s.draw_count)) return 1;
     if (r->materials.upload(s.materials, s.material_count)) return 1;
     if (r->transforms.upload(s.global_transforms, (size_t)s.transform_count * 16)) return 1;
-    if (r->draw_lod.alloc(s.draw_count)) return 1;
+    if (r->draw_lod.alloc(s.draw_count) || r->draw_visible.alloc(std::max<size_t>(s.draw_count, 1)) ||
+        r->meshlet_bits.alloc(((size_t)s.meshlet_visibility_count + 31) / 32 + 1)) return 1;
+    // nothing was visible "last frame": the first frame's early phase draws nothing, its late phase everything
+    RDR_HIP(hipMemset(r->draw_visible.ptr, 0, r->draw_visible.count));
+    RDR_HIP(hipMemset(r->meshlet_bits.ptr, 0, r->meshlet_bits.count * sizeof(uint32_t)));
     RDR_HIP(hipMemset(r->draw_lod.ptr, 0xFF, std::max<size_t>(s.draw_count, 1)));
 
     // meshlet instance -> draw, and work-list capacities

@@ -14,8 +14,11 @@
 // transformed vertices in LDS, and a 64-bit atomic min per covered sample in
 // place of ROPs + a depth buffer.
 //
-// The reference's early/late occlusion split is a conservative optimisation
-// that does not change the image; one pass over every draw is run.
+// The reference's early/late occlusion split (cull.comp.glsl:60-95, shader.task.glsl:
+// 96-128, depth_reduce.comp.glsl) is a conservative optimisation that does not change
+// the image.  With occlusion culling off one pass over every draw is run; with it on,
+// the same two phases run here: what was visible last frame, a depth pyramid of that,
+// then everything else tested against the pyramid.
 #include "rdr_device.h"
 
 namespace {
@@ -25,19 +28,70 @@ constexpr int kSmallExtent = 64 * 256; // bounding boxes up to 64 px on a side s
 constexpr int kTile = 64;              // screen tile of the binned path, pixels
 constexpr int kTileBatch = 64;         // triangle records staged in LDS per round
 
+enum : int { kPhaseSingle = 0, kPhaseEarly = 1, kPhaseLate = 2 };
+
+// Store or, in the late phase, add a per-workgroup statistic.
+RDR_DEV void stat_store(const FrameView& fv, uint32_t slot, uint32_t v) {
+    fv.stat_slots[slot] = fv.stat_accumulate ? fv.stat_slots[slot] + v : v;
+}
+
+// Is everything inside the view-space sphere (c, r) behind what the early phase drew?
+// Follows the reference's test (projectSphere, assets/shaders/math.inc.glsl:5-26; use at
+// cull.comp.glsl:82-94 and shader.task.glsl:103-115) but is strictly conservative, because
+// the result must not change a single key: the sphere is padded (1.6 % of the radius plus
+// 0.1 % of the distance, far above the rounding of the transforms), its screen box is widened
+// by a pixel, the pyramid level is chosen so that the box touches at most 2 x 2 texels, all of
+// which are read, and only a sphere whose nearest depth is strictly below the block minimum
+// is reported.  Spheres that reach the near plane are never reported.
+RDR_DEV bool sphere_occluded(const FrameView& fv, vec3 c, float r) {
+    const rdr_ubo& u = fv.ubo;
+    r = r * 1.015625f + fabsf(c.z) * 0.0009765625f;
+    if (!(c.z > r + u.near_plane)) return false;
+    const float czr2 = c.z * c.z - r * r;
+    const float vx = sqrtf(c.x * c.x + czr2), vy = sqrtf(c.y * c.y + czr2);
+    const float ax = (vx * c.x - c.z * r) / (vx * c.z + c.x * r), bx = (vx * c.x + c.z * r) / (vx * c.z - c.x * r);
+    const float ay = (vy * c.y - c.z * r) / (vy * c.z + c.y * r), by = (vy * c.y + c.z * r) / (vy * c.z - c.y * r);
+    // view-space slopes -> NDC -> framebuffer (x_f = W/2 ndc.x + W/2, y_f = -H/2 ndc.y + H/2)
+    const float W = (float)fv.width, H = (float)fv.height;
+    const float xa = (ax * u.proj[0] * 0.5f + 0.5f) * W, xb = (bx * u.proj[0] * 0.5f + 0.5f) * W;
+    const float ya = (0.5f - ay * u.proj[5] * 0.5f) * H, yb = (0.5f - by * u.proj[5] * 0.5f) * H;
+    const float x_lo = fminf(xa, xb), x_hi = fmaxf(xa, xb), y_lo = fminf(ya, yb), y_hi = fmaxf(ya, yb);
+    if (!(x_lo <= x_hi) || !(y_lo <= y_hi)) return false; // NaN: no statement
+    const int ix0 = max((int)floorf(clampf(x_lo, -4.0f, W + 4.0f)) - 1, 0), ix1 = min((int)floorf(clampf(x_hi, -4.0f, W + 4.0f)) + 1, (int)fv.width - 1);
+    const int iy0 = max((int)floorf(clampf(y_lo, -4.0f, H + 4.0f)) - 1, 0), iy1 = min((int)floorf(clampf(y_hi, -4.0f, H + 4.0f)) + 1, (int)fv.height - 1);
+    if (ix0 > ix1 || iy0 > iy1) return false; // off screen: the frustum tests decide
+    const uint32_t span = (uint32_t)max(ix1 - ix0, iy1 - iy0) + 1u;
+    // smallest level whose texels (2^(l+1) pixels) are at least `span` wide: the box then touches <= 2 per axis
+    uint32_t l = span <= 2u ? 0u : 31u - (uint32_t)__clz((int)(span - 1u));
+    l = min(l, fv.pyr_levels - 1u);
+    const uint32_t sh = l + 1u;
+    const uint32_t tx0 = (uint32_t)ix0 >> sh, tx1 = (uint32_t)ix1 >> sh, ty0 = (uint32_t)iy0 >> sh, ty1 = (uint32_t)iy1 >> sh;
+    const uint32_t* lv = fv.pyramid + fv.pyr_offset[l];
+    const uint32_t pw = fv.pyr_w[l];
+    uint32_t far_bits = 0xFFFFFFFFu;
+    for (uint32_t ty = ty0; ty <= ty1; ++ty)
+        for (uint32_t tx = tx0; tx <= tx1; ++tx) far_bits = min(far_bits, lv[ty * pw + tx]);
+    const float nearest = u.near_plane / (c.z - r); // depth = near / view z (reverse-Z, infinite far plane)
+    return nearest < __uint_as_float(far_bits);
+}
+
 // ------------------------------------------------------------------------------
-// Draw cull
+// Draw cull.  PHASE: single pass; early (draws visible last frame only, opaque only);
+// late (every draw, opaque ones tested against the pyramid; masked draws are emitted
+// here and only here, as in the reference's separate mask pass).
 // ------------------------------------------------------------------------------
+template <int PHASE>
 __global__ __launch_bounds__(256) void k_draw_cull(SceneView sv, FrameView fv) {
     const uint32_t di = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = lane_id();
     const rdr_ubo& u = fv.ubo;
 
-    uint32_t ncmd = 0, k_lo = 0, k_hi = 0, lod_meshlet_offset = 0, vis_off = 0;
+    uint32_t ncmd = 0, k_lo = 0, k_hi = 0, lod_meshlet_offset = 0, vis_off = 0, was_visible = 0;
     float max_scale = 0.0f;
     bool emitted = false;
     if (di < sv.draw_count) {
         const rdr_mesh_draw d = sv.draws[di];
+        if (PHASE != kPhaseSingle) was_visible = fv.draw_visible[di];
         const rdr_mesh* mesh = &sv.meshes[d.mesh_index];
         float model[16];
         load_m4(sv.transforms + (size_t)d.model_index * 16, model);
@@ -51,9 +105,15 @@ __global__ __launch_bounds__(256) void k_draw_cull(SceneView sv, FrameView fv) {
         visible = visible && (c.z * -u.frustum[1] + fabsf(c.x) * u.frustum[0] < radius);
         visible = visible && (c.z * -u.frustum[3] + fabsf(c.y) * u.frustum[2] < radius);
         visible = visible && (c.z + radius > -u.near_plane) && (c.z + radius < u.far_plane);
+        if (PHASE == kPhaseLate) {
+            if (visible && d.alpha_mode != 1u) visible = !sphere_occluded(fv, c, radius);
+            fv.draw_visible[di] = visible ? 1 : 0;
+        }
+        bool emit = visible || d.alpha_mode == 1u;
+        if (PHASE == kPhaseEarly) emit = visible && was_visible != 0u && d.alpha_mode != 1u;
 
         uint32_t lod = 0xFFu;
-        if (visible || d.alpha_mode == 1u) {
+        if (emit) {
             uint32_t lod_index = 0;
             const float threshold = fmaxf(len3(c) - radius, 0.0f) * u.lod_target / max_scale;
             const uint32_t lod_count = mesh->lod_count;
@@ -72,7 +132,7 @@ __global__ __launch_bounds__(256) void k_draw_cull(SceneView sv, FrameView fv) {
             }
             emitted = true;
         }
-        sv.draw_lod[di] = (uint8_t)lod;
+        if (PHASE != kPhaseEarly) sv.draw_lod[di] = (uint8_t)lod; // the late phase sees every draw the early one saw
     }
 
     // wave-level compaction: one atomic per wave reserves the commands of 64 draws
@@ -90,7 +150,8 @@ __global__ __launch_bounds__(256) void k_draw_cull(SceneView sv, FrameView fv) {
         cmd.count = min(64u, k_hi - k_lo - i * 64u);
         cmd.instance_first = vis_off + k_lo + i * 64u;
         cmd.max_scale = max_scale;
-        cmd._pad[0] = cmd._pad[1] = cmd._pad[2] = 0;
+        cmd.late_draw_visibility = was_visible;
+        cmd._pad[0] = cmd._pad[1] = 0;
         fv.commands[slot] = cmd;
     }
     if (fv.collect_stats) {
@@ -98,7 +159,7 @@ __global__ __launch_bounds__(256) void k_draw_cull(SceneView sv, FrameView fv) {
         const uint32_t n = wave_sum(emitted ? 1u : 0u);
         if (lane == 0) wg_emitted[threadIdx.x >> 6] = n;
         __syncthreads();
-        if (threadIdx.x == 0)
+        if (threadIdx.x == 0 && PHASE != kPhaseEarly) // draws_visible: what the single / late phase emitted
             fv.stat_slots[fv.grid.slot_draw + blockIdx.x] = wg_emitted[0] + wg_emitted[1] + wg_emitted[2] + wg_emitted[3];
     }
 }
@@ -107,6 +168,7 @@ __global__ __launch_bounds__(256) void k_draw_cull(SceneView sv, FrameView fv) {
 // Meshlet cull: one wave per command, one lane per meshlet; the 16 waves of a
 // workgroup reserve their output slots with a single atomic.
 // ------------------------------------------------------------------------------
+template <int PHASE>
 __global__ __launch_bounds__(1024) void k_meshlet_cull(SceneView sv, FrameView fv) {
     __shared__ uint32_t wave_count[16];
     __shared__ uint32_t wave_masked[16];
@@ -122,6 +184,7 @@ __global__ __launch_bounds__(1024) void k_meshlet_cull(SceneView sv, FrameView f
         bool accept = false;
         uint32_t draw_id = 0, first = 0, instance_first = 0, tri_count = 0, count = 0, masked = 0;
         uint32_t model_index = 0, mesh_vertex_offset = 0, m_vertex_offset = 0, m_triangle_offset = 0, m_counts = 0;
+        bool emit = false;
         if (ci < cmd_count) {
             const CullCommand* cp = &fv.commands[__builtin_amdgcn_readfirstlane(ci)];
             draw_id = cp->draw_id; first = cp->meshlet_first; count = cp->count;
@@ -152,8 +215,28 @@ __global__ __launch_bounds__(1024) void k_meshlet_cull(SceneView sv, FrameView f
                 accept = accept && (cc.z * -u.frustum[1] + cc.x * u.frustum[0] < radius);
                 accept = accept && (cc.z * -u.frustum[3] + cc.y * u.frustum[2] < radius);
                 accept = accept && (cc.z + radius > -u.near_plane) && (cc.z + radius < u.far_plane);
+                emit = accept;
+                if (PHASE != kPhaseSingle) {
+                    // one bit per meshlet instance: accepted by last frame's late phase
+                    const uint32_t bit_index = instance_first + lane;
+                    uint32_t* word = &fv.meshlet_bits[bit_index >> 5];
+                    const uint32_t bit = 1u << (bit_index & 31u);
+                    const bool was = (*word & bit) != 0u;
+                    if (PHASE == kPhaseEarly) {
+                        emit = accept = accept && was;
+                    } else {
+                        if (accept && !masked) accept = !sphere_occluded(fv, cc, radius);
+                        if (!masked && accept != was) { // steady state: no atomics at all
+                            if (accept) atomicOr(word, bit);
+                            else atomicAnd(word, ~bit);
+                        }
+                        // already drawn by the early phase: its draw was visible and its bit was set
+                        emit = accept && !(cp->late_draw_visibility != 0u && was && !masked);
+                    }
+                }
             }
         }
+        accept = emit;
         const unsigned long long mask = __ballot(accept);
         const uint32_t n_acc = (uint32_t)__popcll(mask);
         if (lane == 0) { wave_count[wave] = n_acc; wave_masked[wave] = masked; }
@@ -184,9 +267,11 @@ __global__ __launch_bounds__(1024) void k_meshlet_cull(SceneView sv, FrameView f
             }
         }
         __syncthreads(); // wave_count is rewritten next iteration
-        st_tested += lane == 0 ? count : 0u;
+        if (PHASE != kPhaseEarly) { // the late phase tests everything the early one did
+            st_tested += lane == 0 ? count : 0u;
+            st_tris += tri_count;
+        }
         st_visible += lane == 0 ? n_acc : 0u;
-        st_tris += tri_count;
     }
     if (fv.collect_stats) {
         __shared__ uint32_t wg_stats[3];
@@ -199,7 +284,7 @@ __global__ __launch_bounds__(1024) void k_meshlet_cull(SceneView sv, FrameView f
             atomicAdd(&wg_stats[2], c);
         }
         __syncthreads();
-        if (threadIdx.x < 3) fv.stat_slots[fv.grid.slot_cull + blockIdx.x * kCullSlots + threadIdx.x] = wg_stats[threadIdx.x];
+        if (threadIdx.x < 3) stat_store(fv, fv.grid.slot_cull + blockIdx.x * kCullSlots + threadIdx.x, wg_stats[threadIdx.x]);
     }
 }
 
@@ -625,10 +710,11 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
         }
     }
     if (fv.collect_stats) {
-        const uint32_t a = wave_sum(st_tested), b = wave_sum(st_raster), c = wave_sum(st_big), f = wave_sum(st_frags);
-        const uint32_t v = wave_sum(st_verts);
+        uint32_t a = wave_sum(st_tested), b = wave_sum(st_raster), c = wave_sum(st_big), f = wave_sum(st_frags);
+        uint32_t v = wave_sum(st_verts);
         if (lane == 0) {
             uint32_t* slot = fv.stat_slots + fv.grid.slot_raster + (blockIdx.x + (MASK ? fv.grid.raster_blocks : 0u)) * kRasterSlots;
+            if (fv.stat_accumulate) { a += slot[0]; b += slot[1]; c += slot[2]; f += slot[3]; v += slot[4]; }
             slot[0] = a; slot[1] = b; slot[2] = c; slot[3] = f; slot[4] = v;
         }
     }
@@ -681,7 +767,7 @@ __global__ __launch_bounds__(256) void k_mid_raster(SceneView sv, FrameView fv) 
         const uint32_t f = wave_sum(frags);
         if (lane == 0) wg_frags[threadIdx.x >> 6] = f;
         __syncthreads();
-        if (threadIdx.x == 0) fv.stat_slots[fv.grid.slot_mid + blockIdx.x] = wg_frags[0] + wg_frags[1] + wg_frags[2] + wg_frags[3];
+        if (threadIdx.x == 0) stat_store(fv, fv.grid.slot_mid + blockIdx.x, wg_frags[0] + wg_frags[1] + wg_frags[2] + wg_frags[3]);
     }
 }
 
@@ -1032,7 +1118,98 @@ __global__ __launch_bounds__(256) void k_tile_raster(SceneView sv, FrameView fv)
         const uint32_t f = wave_sum(frags);
         if ((threadIdx.x & 63u) == 0) wg_frags[threadIdx.x >> 6] = f;
         __syncthreads();
-        if (threadIdx.x == 0) fv.stat_slots[fv.grid.slot_deferred + blockIdx.x] = wg_frags[0] + wg_frags[1] + wg_frags[2] + wg_frags[3];
+        if (threadIdx.x == 0) stat_store(fv, fv.grid.slot_deferred + blockIdx.x, wg_frags[0] + wg_frags[1] + wg_frags[2] + wg_frags[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------
+// Depth pyramid of the early phase (the reference's depth_reduce.comp.glsl with a MIN
+// sampler, renderer/src/renderer/pass.rs:273-393), built from the visibility keys: depth
+// bits = 0x7FFFFFFF - (key >> 32), 0 where nothing was drawn.  Positive floats order like
+// their bit patterns, so levels hold raw bits and reduce with an integer min.
+// k_pyramid_tiles: one workgroup per 64x64 pixels writes levels 0..5 of its region (a thread
+// owns 4x4 pixels); k_pyramid_top: one workgroup finishes the remaining levels.
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pyramid_tiles(FrameView fv) {
+    __shared__ uint32_t lds[256];
+    const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
+    const uint32_t bx0 = blockIdx.x * 64u + tx * 4u, by0 = blockIdx.y * 64u + ty * 4u;
+    uint32_t q[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}; // the block's 2x2 level-0 texels
+    if (bx0 < fv.width && by0 < fv.height) {
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            if (by0 + j >= fv.height) continue;
+            const unsigned long long* row = fv.vis + (size_t)(by0 + j) * fv.width + bx0;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                if (bx0 + i >= fv.width) continue;
+                const uint32_t d = 0x7FFFFFFFu - (uint32_t)(row[i] >> 32);
+                uint32_t& t = q[(j >> 1) * 2u + (i >> 1)];
+                t = min(t, d);
+            }
+        }
+        // level 0: 2x2 texels per thread
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t x = (bx0 >> 1) + (k & 1u), y = (by0 >> 1) + (k >> 1);
+            if (x < fv.pyr_w[0] && y < fv.pyr_h[0]) fv.pyramid[fv.pyr_offset[0] + y * fv.pyr_w[0] + x] = q[k];
+        }
+    }
+    uint32_t v = min(min(q[0], q[1]), min(q[2], q[3])); // level 1: one texel per thread, 16x16 per workgroup
+    if (fv.pyr_levels > 1u) {
+        const uint32_t x = bx0 >> 2, y = by0 >> 2;
+        if (x < fv.pyr_w[1] && y < fv.pyr_h[1]) fv.pyramid[fv.pyr_offset[1] + y * fv.pyr_w[1] + x] = v;
+    }
+    // levels 2..5: 8x8, 4x4, 2x2, 1x1 texels per workgroup, reduced through LDS
+    uint32_t n = 16u; // side of the grid currently held in lds
+    lds[ty * 16u + tx] = v;
+    __syncthreads();
+    for (uint32_t l = 2; l <= 5u && l < fv.pyr_levels; ++l) {
+        const uint32_t half = n >> 1;
+        uint32_t r = 0xFFFFFFFFu;
+        const bool mine = tx < half && ty < half;
+        if (mine) {
+            const uint32_t* p = &lds[(ty * 2u) * 16u + tx * 2u];
+            r = min(min(p[0], p[1]), min(p[16], p[17]));
+        }
+        __syncthreads();
+        if (mine) {
+            lds[ty * 16u + tx] = r;
+            const uint32_t x = blockIdx.x * half + tx, y = blockIdx.y * half + ty;
+            if (x < fv.pyr_w[l] && y < fv.pyr_h[l]) fv.pyramid[fv.pyr_offset[l] + y * fv.pyr_w[l] + x] = r;
+        }
+        __syncthreads();
+        n = half;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_pyramid_top(FrameView fv) {
+    for (uint32_t l = 6; l < fv.pyr_levels; ++l) {
+        const uint32_t w = fv.pyr_w[l], h = fv.pyr_h[l], pw = fv.pyr_w[l - 1], ph = fv.pyr_h[l - 1];
+        const uint32_t* src = fv.pyramid + fv.pyr_offset[l - 1];
+        uint32_t* dst = fv.pyramid + fv.pyr_offset[l];
+        for (uint32_t i = threadIdx.x; i < w * h; i += blockDim.x) {
+            const uint32_t x = i % w, y = i / w;
+            uint32_t r = 0xFFFFFFFFu;
+            for (uint32_t dy = 0; dy < 2; ++dy)
+                for (uint32_t dx = 0; dx < 2; ++dx) {
+                    const uint32_t sx = 2u * x + dx, sy = 2u * y + dy;
+                    if (sx < pw && sy < ph) r = min(r, src[sy * pw + sx]);
+                }
+            dst[i] = r;
+        }
+        __syncthreads(); // one workgroup: the level just written is visible to all its threads
+    }
+}
+
+// Between the phases: empty the work lists the early phase filled.
+__global__ __launch_bounds__(256) void k_phase_reset(FrameView fv) {
+    const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi < fv.tiles_x * fv.tiles_y) fv.tile_count[gi] = 0u;
+    if (gi == 0) {
+        FrameCounters* c = fv.counters;
+        c->cmd_count = 0; c->vis_count = 0; c->vis_mask_count = 0; c->deferred_count = 0;
+        c->setup_count = 0; c->mid_count = 0; c->bin_total = 0;
     }
 }
 
@@ -1075,7 +1252,7 @@ int rdr_geometry_residency(GeometryResidency* out) {
     int device = 0, cus = 0, n = 0;
     RDR_HIP(hipGetDevice(&device));
     RDR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-    RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_meshlet_cull, 1024, 0));
+    RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_meshlet_cull<kPhaseLate>, 1024, 0));
     out->meshlet_cull = (uint32_t)(n * cus);
     RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_raster<false>, 64, 0));
     out->raster = (uint32_t)(n * cus);
@@ -1092,21 +1269,42 @@ int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t st
     if (ev) RDR_HIP(hipEventRecord(ev[0], stream));
     hipLaunchKernelGGL(k_clear, dim3(clear_blocks), dim3(256), 0, stream, fv.vis, npx, fv.counters, fv.tile_count, fv.tiles_x * fv.tiles_y);
     if (ev) RDR_HIP(hipEventRecord(ev[1], stream));
-    if (sv.draw_count) {
-        hipLaunchKernelGGL(k_draw_cull, dim3(fv.grid.draw_blocks), dim3(256), 0, stream, sv, fv);
-        if (ev) RDR_HIP(hipEventRecord(ev[2], stream));
+    // one pass of the rasterisers over the current work lists
+    auto raster_lists = [&](const FrameView& f, hipEvent_t* mid_event) {
         // persistent grids: the work-list lengths live in device memory
-        hipLaunchKernelGGL(k_meshlet_cull, dim3(fv.grid.cull_blocks), dim3(1024), 0, stream, sv, fv);
+        hipLaunchKernelGGL(k_raster<false>, dim3(f.grid.raster_blocks), dim3(64), 0, stream, sv, f);
+        hipLaunchKernelGGL(k_raster<true>, dim3(f.grid.raster_mask_blocks), dim3(64), 0, stream, sv, f);
+        hipLaunchKernelGGL(k_mid_raster, dim3(f.grid.mid_blocks), dim3(256), 0, stream, sv, f);
+        if (mid_event) (void)hipEventRecord(*mid_event, stream);
+        hipLaunchKernelGGL(k_tile_setup, dim3(256), dim3(256), 0, stream, sv, f);
+        hipLaunchKernelGGL(k_tile_bin<false>, dim3(512), dim3(256), 0, stream, f);
+        hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, f);
+        hipLaunchKernelGGL(k_tile_bin<true>, dim3(512), dim3(256), 0, stream, f);
+        hipLaunchKernelGGL(k_tile_raster, dim3(f.grid.deferred_blocks), dim3(256), 0, stream, sv, f);
+    };
+    if (sv.draw_count && !fv.occlusion) {
+        hipLaunchKernelGGL(k_draw_cull<kPhaseSingle>, dim3(fv.grid.draw_blocks), dim3(256), 0, stream, sv, fv);
+        if (ev) RDR_HIP(hipEventRecord(ev[2], stream));
+        hipLaunchKernelGGL(k_meshlet_cull<kPhaseSingle>, dim3(fv.grid.cull_blocks), dim3(1024), 0, stream, sv, fv);
         if (ev) RDR_HIP(hipEventRecord(ev[3], stream));
-        hipLaunchKernelGGL(k_raster<false>, dim3(fv.grid.raster_blocks), dim3(64), 0, stream, sv, fv);
-        hipLaunchKernelGGL(k_raster<true>, dim3(fv.grid.raster_mask_blocks), dim3(64), 0, stream, sv, fv);
-        hipLaunchKernelGGL(k_mid_raster, dim3(fv.grid.mid_blocks), dim3(256), 0, stream, sv, fv);
-        if (ev) RDR_HIP(hipEventRecord(ev[4], stream));
-        hipLaunchKernelGGL(k_tile_setup, dim3(256), dim3(256), 0, stream, sv, fv);
-        hipLaunchKernelGGL(k_tile_bin<false>, dim3(512), dim3(256), 0, stream, fv);
-        hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, fv);
-        hipLaunchKernelGGL(k_tile_bin<true>, dim3(512), dim3(256), 0, stream, fv);
-        hipLaunchKernelGGL(k_tile_raster, dim3(fv.grid.deferred_blocks), dim3(256), 0, stream, sv, fv);
+        raster_lists(fv, ev ? &ev[4] : nullptr);
+        if (ev) RDR_HIP(hipEventRecord(ev[5], stream));
+    } else if (sv.draw_count) {
+        // early phase: what last frame's late phase found visible (opaque draws only)
+        hipLaunchKernelGGL(k_draw_cull<kPhaseEarly>, dim3(fv.grid.draw_blocks), dim3(256), 0, stream, sv, fv);
+        if (ev) RDR_HIP(hipEventRecord(ev[2], stream));
+        hipLaunchKernelGGL(k_meshlet_cull<kPhaseEarly>, dim3(fv.grid.cull_blocks), dim3(1024), 0, stream, sv, fv);
+        if (ev) RDR_HIP(hipEventRecord(ev[3], stream));
+        raster_lists(fv, ev ? &ev[4] : nullptr);
+        // pyramid of its depth, then everything else against the pyramid; timed with the tile path
+        hipLaunchKernelGGL(k_pyramid_tiles, dim3(fv.tiles_x, fv.tiles_y), dim3(256), 0, stream, fv);
+        hipLaunchKernelGGL(k_pyramid_top, dim3(1), dim3(1024), 0, stream, fv);
+        hipLaunchKernelGGL(k_phase_reset, dim3((fv.tiles_x * fv.tiles_y + 255u) / 256u), dim3(256), 0, stream, fv);
+        FrameView late = fv;
+        late.stat_accumulate = 1u;
+        hipLaunchKernelGGL(k_draw_cull<kPhaseLate>, dim3(late.grid.draw_blocks), dim3(256), 0, stream, sv, late);
+        hipLaunchKernelGGL(k_meshlet_cull<kPhaseLate>, dim3(late.grid.cull_blocks), dim3(1024), 0, stream, sv, late);
+        raster_lists(late, nullptr);
         if (ev) RDR_HIP(hipEventRecord(ev[5], stream));
     }
     RDR_HIP(hipGetLastError());

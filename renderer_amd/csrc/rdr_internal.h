@@ -36,7 +36,9 @@ struct CullCommand {
     uint32_t count;          // 1..64
     uint32_t instance_first; // meshlet-instance id of lane 0
     float max_scale;         // largest column length of the draw's model matrix
-    uint32_t _pad[3];
+    uint32_t late_draw_visibility; // occlusion culling, late phase: the draw was visible last frame (so its
+                                   // meshlets with their bit set were already drawn by the early phase)
+    uint32_t _pad[2];
 };
 static_assert(sizeof(CullCommand) == 32, "CullCommand must be 32 bytes");
 
@@ -221,6 +223,16 @@ struct FrameView {
     // for larger or clipped triangles) it goes to the tile path.
     uint32_t lane_max_pixels, mid_max_pixels;
     uint32_t skybox; // 1: uncovered pixels get the skybox (k_skybox) instead of the clear colour
+    // Two-phase occlusion culling (result-neutral): state kept from the previous frame and the
+    // depth pyramid of the early phase.  Level l holds, per 2^(l+1) x 2^(l+1) pixel block, the
+    // smallest (farthest) depth bits of the block's pixels; the last level is 1 x 1.
+    uint32_t occlusion;        // 1: run early phase -> pyramid -> late phase
+    uint32_t stat_accumulate;  // 1: kernels add to their statistics slots (late phase) instead of storing
+    uint8_t* draw_visible;     // per draw: passed the late phase's tests last frame
+    uint32_t* meshlet_bits;    // per meshlet instance: 1 bit, accepted by the late phase last frame
+    uint32_t* pyramid;
+    uint32_t pyr_levels;
+    uint32_t pyr_offset[16], pyr_w[16], pyr_h[16];
     uint32_t lds_stack_limit; // entries of the LDS traversal stack in use (<= 24; lowered only by tests)
     // Per-workgroup statistics: every workgroup stores its partial counts in its own
     // slot with plain stores (no contended atomics); the host sums the slots on request.

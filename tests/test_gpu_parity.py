@@ -22,23 +22,30 @@ def both(oracle, scene, w, h, shade=True, **cfg):
     o.set_scene(scene)
     ovis = o.render_visbuffer()
     g = Renderer(w, h, conf)
+    g.occlusion = bool(conf.cull_enabled)
     g.set_scene(scene)
-    if shade:
-        g.render()
-    else:
-        g.render_visbuffer()
+    for _ in range(2 if g.occlusion else 1):  # second frame: the early phase has last frame's visibility to work with
+        if shade:
+            g.render()
+        else:
+            g.render_visbuffer()
     return o, ovis, g
 
 
-def check_vis(o, ovis, g):
+def check_vis(o, ovis, g, stats=None):
     gvis = g.read_visbuffer_u64()
     diff = int((gvis != ovis).sum())
     assert diff == 0, f"{diff} of {ovis.size} visibility-buffer keys differ"
     assert np.array_equal(g.read_visbuffer(), o.read_visbuffer())
     st = g.stats()
     od = o.stats.as_dict()
+    # with occlusion culling on, the work counters legitimately differ from the single-pass oracle
+    occlusion = getattr(g, "occlusion", True)
+    compare = (not occlusion) if stats is None else stats
     for k in STAT_KEYS:
-        assert st[k] == od[k], (k, st[k], od[k])
+        if compare:
+            assert st[k] == od[k], (k, st[k], od[k])
+    assert st["fragments"] <= od["fragments"] or not occlusion
 
 
 def check_color(o, g, covered_count=None):
@@ -51,10 +58,11 @@ def check_color(o, g, covered_count=None):
         assert g.stats()["pixels_covered"] == covered_count
 
 
+@pytest.mark.parametrize("occlusion", [False, True])
 @pytest.mark.parametrize("w,h", [(64, 36), (256, 144), (333, 187)])
-def test_atrium(oracle, w, h):
+def test_atrium(oracle, w, h, occlusion):
     sc = synth.make_atrium()
-    o, ovis, g = both(oracle, sc, w, h)
+    o, ovis, g = both(oracle, sc, w, h, cull_enabled=occlusion)
     check_vis(o, ovis, g)
     check_color(o, g, int(covered(ovis).sum()))
 
@@ -66,6 +74,7 @@ def test_atrium_other_views(oracle):
     o = oracle.OracleRenderer(w, h, conf)
     o.set_scene(sc)
     g = Renderer(w, h, conf)
+    g.occlusion = bool(conf.cull_enabled)
     g.set_scene(sc)
     views = [Camera((0.0, 1.0, 30.0), (0.0, 0.0, 1.0)), Camera((-8.0, 6.0, 0.0), (-0.7, 0.3, 0.6)),
              Camera((3.0, 0.2, -10.0), (0.3, -0.5, -0.8)), Camera((0.0, 9.5, 0.0), (0.1, 0.99, 0.05))]
@@ -76,10 +85,11 @@ def test_atrium_other_views(oracle):
         check_color(o, g)
 
 
+@pytest.mark.parametrize("occlusion", [False, True])
 @pytest.mark.parametrize("lod", [False, True])
-def test_field(oracle, lod):
+def test_field(oracle, lod, occlusion):
     sc = synth.make_field(150, 4, lods=3)
-    o, ovis, g = both(oracle, sc, 480, 270, lod_enabled=lod)
+    o, ovis, g = both(oracle, sc, 480, 270, lod_enabled=lod, cull_enabled=occlusion)
     check_vis(o, ovis, g)
     check_color(o, g)
 
@@ -114,6 +124,61 @@ def test_raster_routing_is_result_neutral(oracle, monkeypatch, lane_max, mid_max
     sc = synth.make_atrium()
     o, ovis, g = both(oracle, sc, 256, 144, shade=False)
     check_vis(o, ovis, g)
+
+
+def test_occlusion_culling_over_a_camera_path(oracle):
+    """The early phase draws what the previous frame's late phase found visible, so the state
+    carried between frames is exercised by moving the camera (and the sun-independent LOD
+    choice) every frame: each frame's buffer must still be the oracle's, bit for bit."""
+    sc = synth.make_field(200, 3, lods=3, alpha_fraction=0.2)
+    w, h = 400, 225
+    conf = RendererConfig(lod_enabled=True, cull_enabled=True)
+    o = oracle.OracleRenderer(w, h, conf)
+    o.set_scene(sc)
+    g = Renderer(w, h, conf)
+    g.occlusion = True
+    g.set_scene(sc)
+    for k in range(10):
+        a = 0.35 * k
+        cam = Camera((18.0 * np.sin(a), 1.2 + 0.8 * k, -18.0 * np.cos(a)), (np.sin(a), 0.08 * k, -np.cos(a)))
+        ovis = o.render_visbuffer(cam, (0.3, 0.8, -0.4))
+        g.render_visbuffer(cam, (0.3, 0.8, -0.4))
+        assert np.array_equal(g.read_visbuffer_u64(), ovis), f"frame {k}"
+        if k in (3, 7):  # and again from the same place: now everything visible comes from the early phase
+            g.render_visbuffer(cam, (0.3, 0.8, -0.4))
+            assert np.array_equal(g.read_visbuffer_u64(), ovis), f"frame {k} repeated"
+
+
+def test_occlusion_culling_skips_hidden_meshlets(oracle):
+    """A wall in front of the field: same image as without culling, far fewer meshlets rasterised."""
+    sc = synth.make_field(300, 3, lods=1)
+    sc.camera = Camera((0.0, 1.0, -40.0), (0.0, 0.0, -1.0))
+    o = oracle.OracleRenderer(480, 270, RendererConfig())
+    o.set_scene(sc)
+    base = o.render_visbuffer()
+    fwd = np.array([o.ubo.view[2], o.ubo.view[6], o.ubo.view[10]], np.float64)  # the view matrix's forward row
+    right, up = np.array([o.ubo.view[0], o.ubo.view[4], o.ubo.view[8]]), np.array([o.ubo.view[1], o.ubo.view[5], o.ubo.view[9]])
+    c = np.array(sc.camera.position) + 6.0 * fwd
+    quad = [c - 40 * right - 1.0 * up, c + 40 * right - 1.0 * up, c + 40 * right + 30 * up, c - 40 * right + 30 * up]
+    wall = synth.make_triangle_scene([quad[0], quad[1], quad[2]], extra_tris=[[quad[0], quad[2], quad[3]], [quad[0], quad[2], quad[1]],
+                                                                               [quad[0], quad[3], quad[2]]])
+    mesh = sc.append_mesh(wall.vertices, [wall.indices])
+    sc.add_draw(mesh, np.eye(4, dtype=np.float32).reshape(-1), 0, 0)
+    results = {}
+    for occl in (False, True):
+        conf = RendererConfig(cull_enabled=occl)
+        oo = oracle.OracleRenderer(480, 270, conf)
+        oo.set_scene(sc)
+        ovis = oo.render_visbuffer()
+        g = Renderer(480, 270, conf)
+        g.set_scene(sc)
+        for _ in range(3):
+            g.render_visbuffer()
+        assert np.array_equal(g.read_visbuffer_u64(), ovis)
+        results[occl] = g.stats()
+    assert not np.array_equal(ovis, base)  # the wall is in the picture
+    assert results[True]["meshlets_visible"] < 0.5 * results[False]["meshlets_visible"]
+    assert results[True]["triangles_rasterised"] < 0.5 * results[False]["triangles_rasterised"]
 
 
 def test_shadow_deep_stack_path(oracle, monkeypatch):
