@@ -211,7 +211,8 @@ typedef struct rdr_scene_desc {
  * the GPU (renderer/src/renderer.rs:1182-1183) plus this path's own switches. */
 typedef struct rdr_config {
     uint32_t lod_enabled;
-    uint32_t cull_enabled;   /* accepted; occlusion culling is result-neutral and not run */
+    uint32_t cull_enabled;   /* 1: two-phase occlusion culling (early phase, depth pyramid, late phase;
+                              * cull.comp.glsl:60-95, shader.task.glsl:96-128); never changes the image */
     uint32_t collect_stats;  /* 1: count triangles/fragments per frame (small cost) */
     uint32_t time_kernels;   /* 1: bracket each kernel with events for rdr_get_stats */
     uint32_t skybox;         /* 1: pixels with no geometry show env.skybox (SkyBoxPass,

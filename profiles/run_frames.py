@@ -10,10 +10,10 @@ scene_name = sys.argv[2] if len(sys.argv) > 2 else "field"
 w, h = 3840, 2160
 if scene_name == "field":  # exactly bench.py's single-GPU workload
     scene = synth.make_field(1250, 5, lods=1, with_env=True)
-    conf = RendererConfig(lod_enabled=False, cull_enabled=True, collect_stats=True, time_kernels=True)
+    conf = RendererConfig(lod_enabled=False, cull_enabled=False, collect_stats=True, time_kernels=True)
 else:
     scene = synth.make_atrium(columns=10, spheres=60, sphere_subdiv=5)
-    conf = RendererConfig(collect_stats=True, time_kernels=True)
+    conf = RendererConfig(cull_enabled=os.environ.get("RDR_OCCLUSION", "0") != "0", collect_stats=True, time_kernels=True)
 r = Renderer(w, h, conf)
 r.set_scene(scene)
 for _ in range(frames):
