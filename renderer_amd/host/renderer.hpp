@@ -24,13 +24,14 @@ struct RendererConfig { // scenery/src/lib.rs:7-14, the fields that reach the GP
     bool cull_enabled = true;
     bool collect_stats = false;
     bool time_kernels = false;
+    bool skybox = false; // run the skybox pass on pixels without geometry (renderer/src/renderer/pass.rs:397-445)
 };
 
 class Renderer {
 public:
     Renderer(uint32_t width, uint32_t height, const RendererConfig& cfg = {}, int hip_device = 0)
         : width_(width), height_(height) {
-        rdr_config c{cfg.lod_enabled, cfg.cull_enabled, cfg.collect_stats, cfg.time_kernels};
+        rdr_config c{cfg.lod_enabled, cfg.cull_enabled, cfg.collect_stats, cfg.time_kernels, cfg.skybox};
         check(rdr_create(&c, width, height, &hip_device, 1, &handle_));
     }
     ~Renderer() { rdr_destroy(handle_); }
