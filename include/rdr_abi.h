@@ -316,6 +316,21 @@ int rdr_get_ubo(rdr_renderer* r, rdr_ubo* out);
 void rdr_destroy(rdr_renderer* r);
 const char* rdr_last_error(void);
 
+/* ------------------------------------------------------------------ */
+/* IBL bake: the inputs of rdr_env_desc, produced on the GPU (the      */
+/* reference's offline `bake` tool: bake/src/brdf.rs:12-80 +           */
+/* assets/shaders/brdf.comp.glsl, bake/src/brdf.rs:99-338 +            */
+/* assets/shaders/filter_envmap.frag.glsl).  Stand-alone: no renderer. */
+/* ------------------------------------------------------------------ */
+/* size x size RGBA32F; column x = n.v (x + 0.5) / size, row y = roughness 1 - (y + 0.5) / size;
+ * r, g = GGX split sum, b = Charlie, a = 0.  The reference bakes 256 x 256 with 10 000 samples. */
+int rdr_bake_brdf_lut(int hip_device, uint32_t size, uint32_t samples, float* out_rgba32f);
+/* Prefilter `skybox` into a cubemap of base `size` with `mips` levels (roughness = level /
+ * (mips - 1)), mip-major, face-major RGBA32F.  distribution: 0 Lambertian, 1 GGX, 2 Charlie.
+ * The reference bakes 256, log2(256) = 8 levels, 1024 samples. */
+int rdr_bake_env_map(int hip_device, const rdr_cubemap_desc* skybox, uint32_t distribution, uint32_t size,
+                     uint32_t mips, uint32_t samples, float* out_rgba32f);
+
 #ifdef __cplusplus
 }
 #endif

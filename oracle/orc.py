@@ -36,6 +36,8 @@ def lib():
         L.orc_shade.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.Ubo), C.c_void_p, C.c_void_p, C.c_uint32,
                                 C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_skybox.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.Ubo), C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_bake_brdf_lut.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_bake_env_map.argtypes = [C.POINTER(abi.CubemapDesc), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_num_threads.restype = C.c_int
         _LIB = L
     return _LIB
@@ -109,3 +111,25 @@ class OracleRenderer:
 
 def num_threads():
     return int(lib().orc_num_threads())
+
+
+def bake_brdf_lut(size, samples):
+    """(size, size, 4) float32: CPU restatement of brdf.comp.glsl."""
+    out = np.zeros((size, size, 4), np.float32)
+    assert lib().orc_bake_brdf_lut(size, samples, out.ctypes.data) == 0
+    return out
+
+
+def bake_env_map(skybox, distribution, size, mips, samples):
+    """List of (6, n, n, 4) float32 levels: CPU restatement of filter_envmap.frag.glsl."""
+    from renderer_amd.bake import cubemap_desc
+    keep = []
+    desc = cubemap_desc(skybox, keep)
+    sizes = [max(1, size >> l) for l in range(mips)]
+    out = np.zeros(sum(6 * n * n for n in sizes) * 4, np.float32)
+    assert lib().orc_bake_env_map(C.byref(desc), distribution, size, mips, samples, out.ctypes.data) == 0
+    levels, off = [], 0
+    for n in sizes:
+        levels.append(out[off:off + 6 * n * n * 4].reshape(6, n, n, 4).copy())
+        off += 6 * n * n * 4
+    return levels

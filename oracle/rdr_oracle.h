@@ -39,6 +39,14 @@ int orc_shade(const rdr_scene_desc* scene, const rdr_ubo* ubo, const uint64_t* v
 int orc_skybox(const rdr_scene_desc* scene, const rdr_ubo* ubo, const uint64_t* vis,
                uint32_t row_lo, uint32_t row_hi, uint8_t* out_rgba8);
 
+/* IBL bake (bake/src/brdf.rs, brdf.comp.glsl, filter_envmap.frag.glsl).  The LUT is size x size
+ * RGBA32F, row y = roughness 1 - (y + 0.5) / size, column x = n.v (x + 0.5) / size.  The
+ * prefiltered map is mip-major, face-major RGBA32F, base `size`, `mips` levels, roughness =
+ * level / (mips - 1); distribution 0 = Lambertian, 1 = GGX, 2 = Charlie. */
+int orc_bake_brdf_lut(uint32_t size, uint32_t samples, float* out_rgba32f);
+int orc_bake_env_map(const rdr_cubemap_desc* skybox, uint32_t distribution, uint32_t size, uint32_t mips,
+                     uint32_t samples, float* out_rgba32f);
+
 int orc_num_threads(void);
 
 #ifdef __cplusplus

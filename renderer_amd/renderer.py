@@ -19,6 +19,7 @@ ABI_SYMBOLS = [
     "rdr_set_partition", "rdr_set_shade_rows", "rdr_visbuffer_device_ptr", "rdr_color_device_ptr",
     "rdr_set_stream", "rdr_sync", "rdr_read_visbuffer", "rdr_read_visbuffer_u64", "rdr_read_color",
     "rdr_get_stats", "rdr_build_ubo", "rdr_get_ubo", "rdr_destroy", "rdr_last_error",
+    "rdr_bake_brdf_lut", "rdr_bake_env_map",
 ]
 
 _LIB = None
@@ -45,6 +46,8 @@ def load_library():
     L.rdr_render.argtypes = [vp, f3, f3, f3]
     L.rdr_render_visbuffer.argtypes = [vp, f3, f3, f3]
     L.rdr_shade.argtypes = [vp]
+    L.rdr_bake_brdf_lut.argtypes = [C.c_int, C.c_uint32, C.c_uint32, vp]
+    L.rdr_bake_env_map.argtypes = [C.c_int, C.POINTER(abi.CubemapDesc), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     L.rdr_set_partition.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.rdr_set_shade_rows.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.rdr_visbuffer_device_ptr.argtypes = [vp]
