@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--instances", type=int, default=1250, help="instances per GPU")
     ap.add_argument("--subdivisions", type=int, default=5)
-    ap.add_argument("--cpu-frames", type=int, default=3, help="CPU-baseline frames (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=40, help="CPU-baseline frames, about 10 s of CPU work (0 = skip)")
     ap.add_argument("--secondary-frames", type=int, default=50,
                     help="single GPU only: frames for the secondary series (LOD on, alpha-masked, atrium); 0 = skip")
     ap.add_argument("--composite", choices=("auto", "reduce_scatter", "all_reduce"), default="auto",
