@@ -532,7 +532,9 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
     {
         // tile path: deferred clip-space triangles, their screen-space records (clipping can fan one
         // triangle into several) and the per-tile bins
-        const size_t n_def = (size_t)std::min<uint64_t>(std::max<uint64_t>(tri_total, 1u << 16), 1u << 21);
+        // at most every LOD-0 triangle, capped at 4 M per frame (about 1.6 GB of lists at the cap; a frame that
+        // needs more reports an overflow error instead of dropping triangles silently)
+        const size_t n_def = (size_t)std::min<uint64_t>(std::max<uint64_t>(tri_total, 1u << 16), 1u << 22);
         if (r->deferred.alloc(n_def) || r->setup.alloc(n_def + n_def / 2) || r->setup_mask.alloc(n_def + n_def / 2) ||
             r->mid.alloc(n_def) || r->mid_mask.alloc(n_def)) return 1;
         if (r->bin_entries.alloc(std::max<size_t>(n_def * 4, (size_t)1 << 22))) return 1;
