@@ -18,7 +18,7 @@ from .scene_bin import load_scene_bin, save_scene_bin
 
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="python -m renderer_amd", description=__doc__.split("\n\n")[0])
-    ap.add_argument("scene", help="path of a scene.bin, or synth:field / synth:atrium")
+    ap.add_argument("scene", help="path of a scene.bin / .gltf / .glb, or synth:field / synth:atrium")
     ap.add_argument("--size", type=int, nargs=2, default=(1280, 720), metavar=("W", "H"))
     ap.add_argument("--camera", type=float, nargs=6, metavar=("PX", "PY", "PZ", "DX", "DY", "DZ"))
     ap.add_argument("--sun", type=float, nargs=3)
@@ -35,6 +35,9 @@ def main(argv=None):
         scene = synth.make_field(1250, 5, lods=3, with_env=True)
     elif args.scene == "synth:atrium":
         scene = synth.make_atrium(columns=10, spheres=60, sphere_subdiv=5)
+    elif args.scene.lower().endswith((".gltf", ".glb")):
+        from .gltf import load_gltf
+        scene = load_gltf(args.scene, env=synth.default_env())  # IBL inputs: the synthetic sky (see renderer_amd.bake for real ones)
     else:
         scene = load_scene_bin(args.scene)
     if args.camera:
