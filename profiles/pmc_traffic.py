@@ -30,7 +30,7 @@ for k, c in acc.items():
 # the bench's "raster" bracket holds both instantiations and the mid-size pass
 merged = defaultdict(int)
 for k, v in kernels.items():
-    name = "raster" if k.startswith("raster<") or k == "mid_raster" else k
+    name = "raster" if k.startswith("raster<") or k == "mid_raster" else k.split("<")[0]  # template instantiations together
     merged[name] += v
 out = {
     "workload": workload,
