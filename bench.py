@@ -94,6 +94,30 @@ def secondary_series(W, H, frames, instances, subdivisions):
                     "Mtri_per_s_rasterised": st["triangles_rasterised"] / dt / 1e6,
                     "fragments": st["fragments"], "pixels_covered": st["pixels_covered"]})
         r.close()
+    # throughput with two frames in flight, as the reference's frame loop keeps up to three
+    # (renderer/src/renderer.rs:919-922): two renderers take turns, each on its own stream
+    scene = synth.make_field(instances, subdivisions, lods=1, with_env=True)
+    conf = RendererConfig(lod_enabled=False, cull_enabled=False, collect_stats=True)
+    pair = [Renderer(W, H, conf), Renderer(W, H, conf)]
+    for r in pair:
+        r.set_scene(scene)
+    for k in range(10):
+        pair[k & 1].render()
+    for r in pair:
+        r.sync()
+    t0 = time.perf_counter()
+    for k in range(2 * frames):
+        pair[k & 1].render()
+    for r in pair:
+        r.sync()
+    dt = (time.perf_counter() - t0) / (2 * frames)
+    st = pair[0].stats()
+    out.append({"workload": "field (the headline workload), two frames in flight on two streams", "frames_per_s": 1.0 / dt,
+                "ms_per_frame": dt * 1e3, "Mtri_per_s_submitted": scene.triangle_count() / dt / 1e6,
+                "Mtri_per_s_rasterised": st["triangles_rasterised"] / dt / 1e6,
+                "fragments": st["fragments"], "pixels_covered": st["pixels_covered"]})
+    for r in pair:
+        r.close()
     torch.cuda.synchronize()
     return out
 
