@@ -1,8 +1,12 @@
 """Frames in flight (SortLastPipeline) on one GPU over RCCL with a world of one rank: the stream
 and buffer rotation must deliver, for every frame, exactly what a plain sequential renderer
-produces.  (Ranks > 1 are covered on the CPU by test_distributed.py; RCCL refuses two ranks on
-one device, so this is the part a one-GPU box can check.)"""
+produces.  RCCL refuses two ranks on one device, so ranks > 1 are rehearsed here with the ranks
+sharing the GPU and gloo carrying the device tensors (all-reduce composite), and on the CPU by
+test_distributed.py."""
 import os
+import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -57,3 +61,33 @@ def test_pipelined_frames_match_sequential(composite):
         pipe.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_sharing_one_gpu_composite_to_the_single_gpu_image(tmp_path, world):
+    """Every rank rasterises its share of the scene on the GPU, the keys are MIN-reduced, each rank
+    shades its rows and gathers the rest: all ranks must end up with the single-GPU image, for
+    frames in flight and for a reused slot."""
+    import sort_last_worker as wk
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [subprocess.Popen([sys.executable, wk.__file__, str(r), str(world), str(port), str(tmp_path)])
+             for r in range(world)]
+    try:
+        codes = [p.wait(timeout=100) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert codes == [0] * world
+    ref = Renderer(wk.W, wk.H, RendererConfig())
+    ref.set_scene(synth.make_atrium())
+    for k, cam in enumerate(wk.CAMERAS):
+        ref.render(Camera(*cam), wk.SUN)
+        expected = ref.read_color().reshape(wk.H, wk.W, 4)
+        for r in range(world):
+            got = np.load(tmp_path / f"color{r}_{k}.npy").reshape(wk.H, wk.W, 4)
+            assert np.array_equal(got, expected), (k, r)
+    ref.close()
