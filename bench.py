@@ -138,6 +138,9 @@ def main():
                     help="exchange step of the sort-last composite (auto: reduce-scatter on RCCL)")
     ap.add_argument("--frames-in-flight", type=int, default=int(os.environ.get("RDR_FRAMES_IN_FLIGHT", "2")),
                     help="multi-GPU only: renderers taking turns so that one frame's exchange overlaps the next frame's raster")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="gloo: rehearsal of the multi-rank path with the ranks sharing the visible GPUs (not a measurement; "
+                         "gloo stalls on 4K device buffers, rehearse with --width 1280 --height 720)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="run the composite / gather collectives even with one rank (rehearsal)")
     args = ap.parse_args()
@@ -148,6 +151,9 @@ def main():
 
     from renderer_amd import Renderer, RendererConfig, synth
 
+    if os.environ.get("RDR_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["RDR_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -155,12 +161,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     multi = world > 1 or args.force_collectives
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     W, H = args.width, args.height
     scene = synth.make_field(args.instances * world, args.subdivisions, lods=1, with_env=True)
@@ -250,7 +261,7 @@ def main():
                 "instances": args.instances * world, "width": W, "height": H,
                 "parallelism": "single GPU" if frame is None else
                                f"sort-last x{world}, u64-min {frame.composite.replace('_', '-')} + row-split shade + RGBA8 all-gather, "
-                               f"{len(frame.slots)} frames in flight",
+                               f"{len(frame.slots)} frames in flight" + ("" if args.backend == "nccl" else " [gloo rehearsal]"),
             },
             "kernel_ms": {k: round(v, 4) for k, v in kms.items() if v > 0},
             "frame_counters": {k: st[k] for k in ("draws_visible", "meshlets_tested", "meshlets_visible",

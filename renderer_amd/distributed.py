@@ -52,8 +52,8 @@ def gather_rows(color, rank, world):
     bounds = [row_range(height, k, world) for k in range(world)]
     sizes = {hi - lo for lo, hi in bounds}
     lo, hi = bounds[rank]
-    if len(sizes) == 1:
-        # equal strips: this rank's rows already sit at their offset of the output buffer
+    if len(sizes) == 1 and dist.get_backend() == "nccl":
+        # equal strips: this rank's rows already sit at their offset of the output buffer (RCCL's in-place form)
         dist.all_gather_into_tensor(color.view(-1), color[lo:hi].reshape(-1))
     else:
         dist.all_gather([color[a:b] for a, b in bounds], color[lo:hi].clone())
