@@ -139,8 +139,8 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=int(os.environ.get("RDR_FRAMES_IN_FLIGHT", "2")),
                     help="multi-GPU only: renderers taking turns so that one frame's exchange overlaps the next frame's raster")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
-                    help="gloo: rehearsal of the multi-rank path with the ranks sharing the visible GPUs (not a measurement; "
-                         "gloo stalls on 4K device buffers, rehearse with --width 1280 --height 720)")
+                    help="gloo: rehearsal of the multi-rank path with the ranks sharing the visible GPUs and the exchange "
+                         "staged through the host (checks the plumbing; not a measurement)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="run the composite / gather collectives even with one rank (rehearsal)")
     args = ap.parse_args()

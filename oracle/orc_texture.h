@@ -139,34 +139,43 @@ static inline int cube_face(v3 d, float* sc, float* tc, float* ma) {
     *sc = -d.x; *tc = -d.y; return 5;
 }
 
-/* Direction through face-space point (a, b) in [-1,1]^2 (may lie outside). */
-static inline v3 cube_dir(int face, float a, float b) {
-    switch (face) {
-    case 0: return v3_make(1.0f, -b, -a);
-    case 1: return v3_make(-1.0f, -b, a);
-    case 2: return v3_make(a, 1.0f, b);
-    case 3: return v3_make(a, -1.0f, -b);
-    case 4: return v3_make(a, -b, 1.0f);
-    default: return v3_make(-a, -b, -1.0f);
+/* Seamless cube edges (Vulkan leaves the exact texel choice to the implementation): a bilinear
+ * footprint reaches at most one texel outside its face.  Texel (i, j) of `face`, i and j in
+ * [-1, n], is replaced by the cube texel that contains its centre once the centre is projected
+ * back onto the cube.  In units of half a texel that centre is an integer vector (major component
+ * +-n, the others 2i+1-n and 2j+1-n), so the face selection of cube_face() and the texel index are
+ * evaluated exactly: texels inside the face map to themselves, edge texels to the neighbouring
+ * face's border row, the corner texel to the border corner of the face that wins cube_face()'s
+ * tie order. */
+static inline void cube_wrap_texel(int* face, int* i, int* j, int n) {
+    int a = 2 * *i + 1 - n, b = 2 * *j + 1 - n;
+    int x, y, z;
+    switch (*face) { /* same convention as the direction of face-space point (a, b) */
+    case 0: x = n; y = -b; z = -a; break;
+    case 1: x = -n; y = -b; z = a; break;
+    case 2: x = a; y = n; z = b; break;
+    case 3: x = a; y = -n; z = -b; break;
+    case 4: x = a; y = -b; z = n; break;
+    default: x = -a; y = -b; z = -n; break;
     }
+    int ax = abs(x), ay = abs(y), az = abs(z), sc, tc;
+    if (ax >= ay && ax >= az) {
+        if (x >= 0) { *face = 0; sc = -z; tc = -y; } else { *face = 1; sc = z; tc = -y; }
+    } else if (ay >= az) {
+        if (y >= 0) { *face = 2; sc = x; tc = z; } else { *face = 3; sc = x; tc = -z; }
+    } else {
+        if (z >= 0) { *face = 4; sc = x; tc = -y; } else { *face = 5; sc = -x; tc = -y; }
+    }
+    /* floor((sc + n) / 2 - 1/2 + 1/2): sc + n - 1 is even for in-face centres; arithmetic shift floors */
+    int ii = (sc + n - 1) >> 1, jj = (tc + n - 1) >> 1;
+    *i = ii < 0 ? 0 : (ii > n - 1 ? n - 1 : ii);
+    *j = jj < 0 ? 0 : (jj > n - 1 ? n - 1 : jj);
 }
 
 static inline v4 cube_fetch(const rdr_cubemap_desc* cm, uint32_t level, int face, int i, int j) {
     int n = (int)mip_dim(cm->size, level);
     size_t tb = texel_bytes(cm->format);
-    if (i < 0 || j < 0 || i >= n || j >= n) {
-        /* Seamless edge: re-project the out-of-face texel centre onto the cube. */
-        float a = ((float)i + 0.5f) / (float)n * 2.0f - 1.0f;
-        float b = ((float)j + 0.5f) / (float)n * 2.0f - 1.0f;
-        v3 d = cube_dir(face, a, b);
-        float sc, tc, ma;
-        face = cube_face(d, &sc, &tc, &ma);
-        float s = 0.5f * (sc / ma + 1.0f), t = 0.5f * (tc / ma + 1.0f);
-        i = (int)floorf(s * (float)n);
-        j = (int)floorf(t * (float)n);
-        if (i < 0) i = 0; if (i > n - 1) i = n - 1;
-        if (j < 0) j = 0; if (j > n - 1) j = n - 1;
-    }
+    cube_wrap_texel(&face, &i, &j, n);
     const uint8_t* base = (const uint8_t*)cm->data + cube_level_offset(cm, level) +
                           (size_t)face * n * n * tb;
     return orc_decode_texel(base + ((size_t)j * n + i) * tb, cm->format);

@@ -197,33 +197,39 @@ RDR_DEV int cube_face(vec3 d, float& sc, float& tc, float& ma) {
     sc = -d.x; tc = -d.y; return 5;
 }
 
-RDR_DEV vec3 cube_dir(int face, float a, float b) {
-    switch (face) {
-    case 0: return mk3(1.0f, -b, -a);
-    case 1: return mk3(-1.0f, -b, a);
-    case 2: return mk3(a, 1.0f, b);
-    case 3: return mk3(a, -1.0f, -b);
-    case 4: return mk3(a, -b, 1.0f);
-    default: return mk3(-a, -b, -1.0f);
+// Seamless edges: a bilinear footprint reaches at most one texel outside its face.  The texel
+// (i, j) of `face`, i and j in [-1, n], is replaced by the texel of the cube that contains its
+// centre once that centre is projected back onto the cube.  In units of half a texel the centre
+// is an integer vector (major component +-n, the others 2i+1-n and 2j+1-n), so face selection and
+// the texel index need no division and no rounding; texels inside the face map to themselves,
+// edge texels to the adjacent face's border row, and the corner texel (both out) to the border
+// corner of the face that wins cube_face's tie order.
+RDR_DEV void cube_wrap_texel(int& face, int& i, int& j, int n) {
+    const int a = 2 * i + 1 - n, b = 2 * j + 1 - n;
+    const int axis = face >> 1;
+    const bool neg = face & 1;
+    const int m = neg ? -n : n;
+    // the integer counterpart of the face -> direction convention (+X, -X, +Y, -Y, +Z, -Z)
+    const int x = axis == 0 ? m : (axis == 2 && neg ? -a : a);
+    const int y = axis == 1 ? m : -b;
+    const int z = axis == 0 ? (neg ? a : -a) : (axis == 1 ? (neg ? -b : b) : m);
+    const int ax = abs(x), ay = abs(y), az = abs(z);
+    int sc, tc;
+    if (ax >= ay && ax >= az) {
+        face = x >= 0 ? 0 : 1; sc = x >= 0 ? -z : z; tc = -y;
+    } else if (ay >= az) {
+        face = y >= 0 ? 2 : 3; sc = x; tc = y >= 0 ? z : -z;
+    } else {
+        face = z >= 0 ? 4 : 5; sc = z >= 0 ? x : -x; tc = -y;
     }
+    i = min(max((sc + n - 1) >> 1, 0), n - 1);
+    j = min(max((tc + n - 1) >> 1, 0), n - 1);
 }
 
 RDR_DEV vec4 cube_fetch(const GpuCubemap& cm, const uint8_t* texels, uint32_t level, int face, int i, int j) {
     const int n = (int)mip_dim(cm.size, level);
     const uint32_t tb = cm.format == RDR_FORMAT_RGBA32F ? 16u : 4u;
-    if (i < 0 || j < 0 || i >= n || j >= n) {
-        // seamless edge: re-project the out-of-face texel centre onto the cube
-        const float a = ((float)i + 0.5f) / (float)n * 2.0f - 1.0f;
-        const float b = ((float)j + 0.5f) / (float)n * 2.0f - 1.0f;
-        const vec3 d = cube_dir(face, a, b);
-        float sc, tc, ma;
-        face = cube_face(d, sc, tc, ma);
-        const float s = 0.5f * (sc / ma + 1.0f), t = 0.5f * (tc / ma + 1.0f);
-        i = (int)floorf(s * (float)n);
-        j = (int)floorf(t * (float)n);
-        i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
-        j = j < 0 ? 0 : (j > n - 1 ? n - 1 : j);
-    }
+    cube_wrap_texel(face, i, j, n);
     const uint8_t* base = texels + cm.offset + cm.level_offset[level] + (size_t)face * n * n * tb;
     return decode_texel(base + ((size_t)j * n + i) * tb, cm.format, nullptr);
 }

@@ -27,9 +27,20 @@ def row_range(height, rank, world):
     return (height * rank) // world, (height * (rank + 1)) // world
 
 
+def _host_staged(t):
+    """gloo moves device tensors through the host anyway (and stalls on large ones): for a device
+    tensor on that backend the collectives below run on an explicit host copy."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
 def composite_min(vis_i64):
     """In-place MIN all-reduce of a visibility buffer viewed as int64."""
     assert vis_i64.dtype == torch.int64
+    if _host_staged(vis_i64):
+        host = vis_i64.cpu()  # synchronises with the current stream
+        dist.all_reduce(host, op=dist.ReduceOp.MIN)
+        vis_i64.copy_(host)
+        return vis_i64
     dist.all_reduce(vis_i64, op=dist.ReduceOp.MIN)
     return vis_i64
 
@@ -55,6 +66,12 @@ def gather_rows(color, rank, world):
     if len(sizes) == 1 and dist.get_backend() == "nccl":
         # equal strips: this rank's rows already sit at their offset of the output buffer (RCCL's in-place form)
         dist.all_gather_into_tensor(color.view(-1), color[lo:hi].reshape(-1))
+    elif _host_staged(color):
+        parts = [torch.empty((b - a,) + tuple(color.shape[1:]), dtype=color.dtype) for a, b in bounds]
+        dist.all_gather(parts, color[lo:hi].cpu())
+        for (a, b), part in zip(bounds, parts):
+            if a != lo:
+                color[a:b].copy_(part)
     else:
         dist.all_gather([color[a:b] for a, b in bounds], color[lo:hi].clone())
     return color
