@@ -273,7 +273,7 @@ GpuImage pack_image(TexelPacker& tp, const rdr_image_desc& im) {
 }
 
 int pack_cubemap(TexelPacker& tp, const rdr_cubemap_desc* cm, GpuCubemap* out) {
-    static const uint8_t black[24] = {0};
+    static const uint8_t black[6 * 3 * 3 * 4] = {0}; // six bordered 1x1 faces
     GpuCubemap g{};
     if (!cm || !cm->data) {
         g.size = 1; g.mip_count = 1; g.format = RDR_FORMAT_RGBA8_UNORM;
@@ -283,14 +283,9 @@ int pack_cubemap(TexelPacker& tp, const rdr_cubemap_desc* cm, GpuCubemap* out) {
     }
     RDR_CHECK(cm->size && cm->mip_count >= 1 && cm->mip_count <= 17, "scene: cubemap dimensions / mip count invalid");
     RDR_CHECK(cm->format == RDR_FORMAT_RGBA8_UNORM || cm->format == RDR_FORMAT_RGBA32F, "scene: cubemap format must be RGBA8_UNORM or RGBA32F");
-    g.size = cm->size; g.mip_count = cm->mip_count; g.format = cm->format;
-    size_t bytes = 0;
-    for (uint32_t l = 0; l < cm->mip_count; ++l) {
-        g.level_offset[l] = (uint32_t)bytes;
-        const size_t n = mip_dim(cm->size, l);
-        bytes += 6 * n * n * texel_bytes(cm->format);
-    }
-    g.offset = tp.append(cm->data, bytes);
+    std::vector<uint8_t> padded;
+    rdr_pack_cubemap(*cm, g, padded);
+    g.offset = tp.append(padded.data(), padded.size());
     *out = g;
     return 0;
 }

@@ -192,14 +192,9 @@ extern "C" int rdr_bake_env_map(int hip_device, const rdr_cubemap_desc* skybox, 
               "rdr_bake_env_map: bad distribution / size / mips / samples");
     RDR_HIP(hipSetDevice(hip_device));
     GpuCubemap g{};
-    g.size = skybox->size; g.mip_count = skybox->mip_count; g.format = skybox->format;
-    const size_t tb = skybox->format == RDR_FORMAT_RGBA32F ? 16 : 4;
-    size_t src_bytes = 0;
-    for (uint32_t l = 0; l < skybox->mip_count; ++l) {
-        g.level_offset[l] = (uint32_t)src_bytes;
-        const size_t n = mip_size(skybox->size, l);
-        src_bytes += 6 * n * n * tb;
-    }
+    std::vector<uint8_t> padded;
+    rdr_pack_cubemap(*skybox, g, padded);
+    const size_t src_bytes = padded.size();
     g.offset = 0;
     size_t out_texels = 0;
     for (uint32_t l = 0; l < mips; ++l) out_texels += (size_t)6 * mip_size(size, l) * mip_size(size, l);
@@ -207,7 +202,7 @@ extern "C" int rdr_bake_env_map(int hip_device, const rdr_cubemap_desc* skybox, 
     float4* out_dev = nullptr;
     RDR_HIP(hipMalloc(&src_dev, src_bytes));
     hipError_t e = hipMalloc(&out_dev, out_texels * sizeof(float4));
-    if (e == hipSuccess) e = hipMemcpy(src_dev, skybox->data, src_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(src_dev, padded.data(), src_bytes, hipMemcpyHostToDevice);
     size_t base = 0;
     for (uint32_t l = 0; l < mips && e == hipSuccess; ++l) {
         const uint32_t n = mip_size(size, l);

@@ -197,43 +197,9 @@ RDR_DEV int cube_face(vec3 d, float& sc, float& tc, float& ma) {
     sc = -d.x; tc = -d.y; return 5;
 }
 
-// Seamless edges: a bilinear footprint reaches at most one texel outside its face.  The texel
-// (i, j) of `face`, i and j in [-1, n], is replaced by the texel of the cube that contains its
-// centre once that centre is projected back onto the cube.  In units of half a texel the centre
-// is an integer vector (major component +-n, the others 2i+1-n and 2j+1-n), so face selection and
-// the texel index need no division and no rounding; texels inside the face map to themselves,
-// edge texels to the adjacent face's border row, and the corner texel (both out) to the border
-// corner of the face that wins cube_face's tie order.
-RDR_DEV void cube_wrap_texel(int& face, int& i, int& j, int n) {
-    const int a = 2 * i + 1 - n, b = 2 * j + 1 - n;
-    const int axis = face >> 1;
-    const bool neg = face & 1;
-    const int m = neg ? -n : n;
-    // the integer counterpart of the face -> direction convention (+X, -X, +Y, -Y, +Z, -Z)
-    const int x = axis == 0 ? m : (axis == 2 && neg ? -a : a);
-    const int y = axis == 1 ? m : -b;
-    const int z = axis == 0 ? (neg ? a : -a) : (axis == 1 ? (neg ? -b : b) : m);
-    const int ax = abs(x), ay = abs(y), az = abs(z);
-    int sc, tc;
-    if (ax >= ay && ax >= az) {
-        face = x >= 0 ? 0 : 1; sc = x >= 0 ? -z : z; tc = -y;
-    } else if (ay >= az) {
-        face = y >= 0 ? 2 : 3; sc = x; tc = y >= 0 ? z : -z;
-    } else {
-        face = z >= 0 ? 4 : 5; sc = z >= 0 ? x : -x; tc = -y;
-    }
-    i = min(max((sc + n - 1) >> 1, 0), n - 1);
-    j = min(max((tc + n - 1) >> 1, 0), n - 1);
-}
-
-RDR_DEV vec4 cube_fetch(const GpuCubemap& cm, const uint8_t* texels, uint32_t level, int face, int i, int j) {
-    const int n = (int)mip_dim(cm.size, level);
-    const uint32_t tb = cm.format == RDR_FORMAT_RGBA32F ? 16u : 4u;
-    cube_wrap_texel(face, i, j, n);
-    const uint8_t* base = texels + cm.offset + cm.level_offset[level] + (size_t)face * n * n * tb;
-    return decode_texel(base + ((size_t)j * n + i) * tb, cm.format, nullptr);
-}
-
+// Cubemaps are stored with a one-texel border around every face (rdr_pack_cubemap in
+// rdr_internal.h): a bilinear footprint reaches at most one texel outside its face, and the border
+// holds the texel that seamless filtering takes there, so all four taps are plain neighbours.
 RDR_DEV vec4 cube_bilinear(const GpuCubemap& cm, const uint8_t* texels, uint32_t level, vec3 d) {
     float sc, tc, ma;
     const int face = cube_face(d, sc, tc, ma);
@@ -242,21 +208,16 @@ RDR_DEV vec4 cube_bilinear(const GpuCubemap& cm, const uint8_t* texels, uint32_t
     const float x = s * (float)n - 0.5f, y = t * (float)n - 0.5f;
     const float fx = floorf(x), fy = floorf(y);
     const float ax = x - fx, ay = y - fy;
-    const int i0 = (int)fx, j0 = (int)fy;
-    vec4 t00, t10, t01, t11;
-    if (i0 >= 0 && j0 >= 0 && i0 + 1 < n && j0 + 1 < n) { // the whole footprint lies inside the face: one address computation
-        const uint32_t tb = cm.format == RDR_FORMAT_RGBA32F ? 16u : 4u;
-        const uint8_t* p = texels + cm.offset + cm.level_offset[level] + ((size_t)face * n * n + (size_t)j0 * n + i0) * tb;
-        t00 = decode_texel(p, cm.format, nullptr);
-        t10 = decode_texel(p + tb, cm.format, nullptr);
-        t01 = decode_texel(p + (size_t)n * tb, cm.format, nullptr);
-        t11 = decode_texel(p + (size_t)n * tb + tb, cm.format, nullptr);
-    } else {
-        t00 = cube_fetch(cm, texels, level, face, i0, j0);
-        t10 = cube_fetch(cm, texels, level, face, i0 + 1, j0);
-        t01 = cube_fetch(cm, texels, level, face, i0, j0 + 1);
-        t11 = cube_fetch(cm, texels, level, face, i0 + 1, j0 + 1);
-    }
+    // -1 .. n-1 for any finite direction; the clamp keeps a non-finite one inside the allocation
+    const int i0 = min(max((int)fx, -1), n - 1), j0 = min(max((int)fy, -1), n - 1);
+    const uint32_t tb = cm.format == RDR_FORMAT_RGBA32F ? 16u : 4u;
+    const size_t pitch = (size_t)(n + 2);
+    const uint8_t* p = texels + cm.offset + cm.level_offset[level] +
+                       (((size_t)face * pitch + (size_t)(j0 + 1)) * pitch + (size_t)(i0 + 1)) * tb;
+    const vec4 t00 = decode_texel(p, cm.format, nullptr);
+    const vec4 t10 = decode_texel(p + tb, cm.format, nullptr);
+    const vec4 t01 = decode_texel(p + pitch * tb, cm.format, nullptr);
+    const vec4 t11 = decode_texel(p + pitch * tb + tb, cm.format, nullptr);
     return lerp4(lerp4(t00, t10, ax), lerp4(t01, t11, ax), ay);
 }
 

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include <string>
 #include <vector>
 
@@ -115,6 +116,8 @@ struct GpuImage {
     uint64_t _pad2;
 };
 
+// A cubemap in device memory: per level six faces of (n + 2) x (n + 2) texels, i.e. each face with
+// a one-texel border (level_offset counts bytes of that padded layout).
 struct GpuCubemap {
     uint32_t size, mip_count, format, _pad;
     uint32_t level_offset[17];
@@ -122,6 +125,71 @@ struct GpuCubemap {
     uint64_t offset;
     uint64_t _pad2;
 };
+
+// Seamless cube edges: texel (i, j) of `face`, i and j in [-1, n], is the cube texel that contains
+// its centre once the centre is projected back onto the cube.  In units of half a texel the centre
+// is an integer vector (major component +-n, the others 2i+1-n and 2j+1-n), so face selection and
+// texel index need no division and no rounding: texels inside the face map to themselves, edge
+// texels to the neighbouring face's border row, the corner texel to the border corner of the face
+// that wins the tie order (x before y before z).  Faces are +X, -X, +Y, -Y, +Z, -Z.
+inline void rdr_cube_wrap_texel(int& face, int& i, int& j, int n) {
+    const int a = 2 * i + 1 - n, b = 2 * j + 1 - n;
+    int x, y, z;
+    switch (face) {
+    case 0: x = n; y = -b; z = -a; break;
+    case 1: x = -n; y = -b; z = a; break;
+    case 2: x = a; y = n; z = b; break;
+    case 3: x = a; y = -n; z = -b; break;
+    case 4: x = a; y = -b; z = n; break;
+    default: x = -a; y = -b; z = -n; break;
+    }
+    const int ax = x < 0 ? -x : x, ay = y < 0 ? -y : y, az = z < 0 ? -z : z;
+    int sc, tc;
+    if (ax >= ay && ax >= az) {
+        if (x >= 0) { face = 0; sc = -z; tc = -y; } else { face = 1; sc = z; tc = -y; }
+    } else if (ay >= az) {
+        if (y >= 0) { face = 2; sc = x; tc = z; } else { face = 3; sc = x; tc = -z; }
+    } else {
+        if (z >= 0) { face = 4; sc = x; tc = -y; } else { face = 5; sc = -x; tc = -y; }
+    }
+    const int ii = (sc + n - 1) >> 1, jj = (tc + n - 1) >> 1;
+    i = ii < 0 ? 0 : (ii > n - 1 ? n - 1 : ii);
+    j = jj < 0 ? 0 : (jj > n - 1 ? n - 1 : jj);
+}
+
+// Re-lay a caller's cubemap (levels of six tightly packed n x n faces) into the bordered device
+// layout; fills g's size, mip_count, format and level_offset (g.offset is the caller's business).
+inline void rdr_pack_cubemap(const rdr_cubemap_desc& cm, GpuCubemap& g, std::vector<uint8_t>& out) {
+    const size_t tb = cm.format == RDR_FORMAT_RGBA32F ? 16 : 4;
+    g.size = cm.size; g.mip_count = cm.mip_count; g.format = cm.format;
+    size_t bytes = 0;
+    for (uint32_t l = 0; l < cm.mip_count; ++l) {
+        const size_t n = (cm.size >> l) ? (cm.size >> l) : 1u;
+        g.level_offset[l] = (uint32_t)bytes;
+        bytes += 6 * (n + 2) * (n + 2) * tb;
+    }
+    out.assign(bytes, 0);
+    const uint8_t* src = static_cast<const uint8_t*>(cm.data);
+    for (uint32_t l = 0; l < cm.mip_count; ++l) {
+        const int n = (int)((cm.size >> l) ? (cm.size >> l) : 1u);
+        const size_t pitch = (size_t)n + 2;
+        uint8_t* dst = out.data() + g.level_offset[l];
+        for (int face = 0; face < 6; ++face) {
+            for (int j = -1; j <= n; ++j) {
+                uint8_t* row = dst + (((size_t)face * pitch + (size_t)(j + 1)) * pitch) * tb;
+                const bool interior = j >= 0 && j < n;
+                if (interior) // one copy for the row's own texels, then only its two border texels
+                    memcpy(row + tb, src + (((size_t)face * n + j) * n) * tb, (size_t)n * tb);
+                for (int i = -1; i <= n; i += interior ? n + 1 : 1) {
+                    int f = face, ii = i, jj = j;
+                    rdr_cube_wrap_texel(f, ii, jj, n);
+                    memcpy(row + (size_t)(i + 1) * tb, src + (((size_t)f * n + jj) * n + ii) * tb, tb);
+                }
+            }
+        }
+        src += (size_t)6 * n * n * tb;
+    }
+}
 
 // Builder-side binary node.
 struct BvhNode {
