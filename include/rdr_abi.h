@@ -331,6 +331,32 @@ int rdr_bake_brdf_lut(int hip_device, uint32_t size, uint32_t samples, float* ou
 int rdr_bake_env_map(int hip_device, const rdr_cubemap_desc* skybox, uint32_t distribution, uint32_t size,
                      uint32_t mips, uint32_t samples, float* out_rgba32f);
 
+/* ------------------------------------------------------------------ */
+/* Mesh preparation on the host: Geometry::append_mesh                  */
+/* (scenery/src/mesh.rs:197-374, which calls the meshoptimizer library): */
+/* vertex de-duplication, vertex cache / fetch ordering, meshlets of at  */
+/* most 64 vertices / 124 triangles (cone weight 0.25) with bounds, and  */
+/* the LOD chain (each level simplified from level 0 to 0.65^k of its    */
+/* indices, relative error limit 0.1, stop at >= 95 % or empty; error =  */
+/* max(level error, previous level's) x mesh extent).  Same rules and    */
+/* limits as the reference; the algorithms are this library's own, so    */
+/* meshlet contents are not identical to meshoptimizer's.  No GPU needed. */
+/* ------------------------------------------------------------------ */
+typedef struct rdr_mesh_builder rdr_mesh_builder;
+typedef struct rdr_built_mesh { /* views into the builder, valid until rdr_mesh_free */
+    const rdr_vertex* vertices;        /* de-duplicated, in fetch order */
+    const uint32_t* indices;           /* level 0 triangle list over `vertices` */
+    const uint32_t* meshlet_vertices;  /* all levels */
+    const uint8_t* meshlet_triangles;  /* all levels; each meshlet padded to 4 bytes */
+    const rdr_meshlet* meshlets;       /* offsets relative to the two arrays above */
+    uint32_t vertex_count, index_count, meshlet_vertex_count, meshlet_triangle_bytes, meshlet_count, _pad;
+    rdr_mesh mesh;                     /* offsets relative to these arrays (vertex_offset = index_offset = 0) */
+} rdr_built_mesh;
+int rdr_mesh_build(const rdr_vertex* vertices, uint32_t vertex_count, const uint32_t* indices, uint32_t index_count,
+                   uint32_t max_lods, rdr_mesh_builder** out);
+int rdr_mesh_result(const rdr_mesh_builder* b, rdr_built_mesh* out);
+void rdr_mesh_free(rdr_mesh_builder* b);
+
 #ifdef __cplusplus
 }
 #endif

@@ -170,6 +170,25 @@ class Config(C.Structure):
                 ("collect_stats", C.c_uint32), ("time_kernels", C.c_uint32), ("skybox", C.c_uint32)]
 
 
+class MeshLod(C.Structure):
+    _fields_ = [("meshlet_offset", C.c_uint32), ("meshlet_count", C.c_uint32), ("error", C.c_float), ("_pad", C.c_uint32)]
+
+
+class Mesh(C.Structure):
+    _fields_ = [("center", C.c_float * 3), ("radius", C.c_float), ("vertex_offset", C.c_uint32), ("vertex_count", C.c_uint32),
+                ("lod_count", C.c_uint32), ("index_offset", C.c_uint32), ("lods", MeshLod * 8)]
+
+
+class BuiltMesh(C.Structure):
+    _fields_ = [("vertices", C.c_void_p), ("indices", C.c_void_p), ("meshlet_vertices", C.c_void_p),
+                ("meshlet_triangles", C.c_void_p), ("meshlets", C.c_void_p),
+                ("vertex_count", C.c_uint32), ("index_count", C.c_uint32), ("meshlet_vertex_count", C.c_uint32),
+                ("meshlet_triangle_bytes", C.c_uint32), ("meshlet_count", C.c_uint32), ("_pad", C.c_uint32),
+                ("mesh", Mesh)]
+
+
+assert C.sizeof(Mesh) == 160
+
 STAT_KERNELS = 8
 KERNEL_NAMES = ["clear", "draw_cull", "meshlet_cull", "raster", "shadow", "big_raster", "shade", "classify"]
 

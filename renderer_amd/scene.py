@@ -118,6 +118,28 @@ class Scene:
         self.meshes = np.concatenate([self.meshes, mesh.reshape(1)])
         return len(self.meshes) - 1
 
+    def append_mesh_auto(self, vertices, indices, max_lods=8):
+        """``Geometry::append_mesh`` (scenery/src/mesh.rs:197-349) from a raw triangle list: the
+        library de-duplicates and reorders the vertices, builds the meshlets and simplifies the
+        LOD chain.  Returns the mesh index."""
+        from .meshprep import build_mesh
+        b = build_mesh(vertices, indices, max_lods)
+        mesh = b.mesh.copy()
+        mesh["vertex_offset"] = len(self.vertices)
+        mesh["index_offset"] = len(self.indices)
+        ml = b.meshlets.copy()
+        ml["vertex_offset"] += len(self.meshlet_vertices)
+        ml["triangle_offset"] += len(self.meshlet_triangles)
+        for li in range(int(mesh["lod_count"])):
+            mesh["lods"][li]["meshlet_offset"] += len(self.meshlets)
+        self.meshlet_vertices = np.concatenate([self.meshlet_vertices, b.meshlet_vertices]).astype(np.uint32)
+        self.meshlet_triangles = np.concatenate([self.meshlet_triangles, b.meshlet_triangles]).astype(np.uint8)
+        self.meshlets = np.concatenate([self.meshlets, ml])
+        self.vertices = np.concatenate([self.vertices, b.vertices])
+        self.indices = np.concatenate([self.indices, b.indices])
+        self.meshes = np.concatenate([self.meshes, mesh.reshape(1)])
+        return len(self.meshes) - 1
+
     def add_draw(self, mesh_index, transform, material_index=0xFFFF, alpha_mode=0):
         """One node + one primitive, as ``build_scene_mesh_draws`` pushes them
         (scenery/src/scene.rs:601-651)."""

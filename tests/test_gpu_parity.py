@@ -304,3 +304,29 @@ def test_full_size_properties():
         g.render_visbuffer()
         acc = np.minimum(acc, g.read_visbuffer_u64())
     assert np.array_equal(acc, full)
+
+
+@pytest.mark.parametrize("lod", [False, True])
+def test_prepared_meshes_with_simplified_lods(oracle, lod):
+    """Meshes that went through the library's mesh preparation (cache-ordered meshlets, simplified
+    LOD chain): instances near and far pick different levels when LOD selection is on."""
+    from renderer_amd.scene import Scene
+    v, lods, _ = synth.icosphere(4, lods=1)
+    gv, gi = synth.grid_mesh(np.array([[-30, -1, -5], [30, -1, -5], [30, -1, 120], [-30, -1, 120]], np.float32), 24, 48)
+    sc = Scene()
+    ball, ground = sc.append_mesh_auto(v, lods[0]), sc.append_mesh_auto(gv, gi)
+    assert int(sc.meshes[ball]["lod_count"]) >= 4
+    sc.add_draw(ground, mat4_trs(), 0xFFFF)
+    rng = np.random.default_rng(5)
+    for k in range(40):
+        z = 2.0 + 2.8 * k
+        sc.add_draw(ball, mat4_trs((rng.uniform(-8, 8), rng.uniform(0, 3), z), scale=(rng.uniform(0.5, 1.5),) * 3), 0xFFFF)
+    sc.env = synth.default_env()
+    sc.camera = Camera((0.0, 3.0, -6.0), (0.0, -0.1, 1.0))
+    o, ovis, g = both(oracle, sc, 384, 216, lod_enabled=lod, cull_enabled=False)
+    check_vis(o, ovis, g)
+    check_color(o, g)
+    if lod:  # fewer triangles submitted than with every instance at level 0
+        full = sc.triangle_count()
+        assert 0 < g.stats()["triangles_submitted"] < full
+    g.close()
