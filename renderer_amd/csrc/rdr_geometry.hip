@@ -655,11 +655,12 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
                 if (mm) {
                     const int leader = __ffsll((long long)mm) - 1;
                     uint32_t base = 0;
-                    if ((int)lane == leader) base = atomicAdd(&fv.counters->mid_count, (uint32_t)__popcll(mm));
+                    const uint32_t seg = blockIdx.x % kMidSegments, seg_capacity = fv.mid_capacity / kMidSegments;
+                    if ((int)lane == leader) base = atomicAdd(&fv.counters->mid_seg[seg * 32u], (uint32_t)__popcll(mm));
                     base = __shfl(base, leader, 64);
                     if (mid) {
-                        const uint32_t slot = base + ballot_rank(mm);
-                        if (slot < fv.mid_capacity) {
+                        const uint32_t in_seg = base + ballot_rank(mm), slot = seg * seg_capacity + in_seg;
+                        if (in_seg < seg_capacity) {
                             SnapVert s0, s1, s2;
                             load_snap(ia, ib, ic, s0, s1, s2);
                             SetupTri t;
@@ -726,10 +727,16 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
 __global__ __launch_bounds__(256) void k_mid_raster(SceneView sv, FrameView fv) {
     __shared__ uint32_t wg_frags[4];
     const uint32_t lane = lane_id();
-    const uint32_t count = min(fv.counters->mid_count, fv.mid_capacity);
+    // the queue is segmented (FrameCounters::mid_seg): lane s holds the running total up to segment s
+    const uint32_t seg_capacity = fv.mid_capacity / kMidSegments;
+    const uint32_t seg_n = lane < kMidSegments ? min(fv.counters->mid_seg[lane * 32u], seg_capacity) : 0u;
+    const uint32_t seg_end = wave_scan_inclusive(seg_n, lane);
+    const uint32_t count = __shfl(seg_end, 63, 64);
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     uint32_t frags = 0;
-    for (uint32_t r = wave; r < count; r += n_waves) {
+    for (uint32_t i = wave; i < count; i += n_waves) {
+        const uint32_t seg = (uint32_t)__popcll(__ballot(lane < kMidSegments && seg_end <= i)); // segments that end at or before i
+        const uint32_t r = seg * seg_capacity + (i - (__shfl(seg_end, (int)seg, 64) - __shfl(seg_n, (int)seg, 64)));
         const SetupTri t = fv.mid[r]; // the same address in every lane: one broadcast load
         TriSetup<int32_t> ts;
         ts.v0 = SnapVert{}; ts.v1 = SnapVert{}; ts.v2 = SnapVert{};
@@ -1209,8 +1216,9 @@ __global__ __launch_bounds__(256) void k_phase_reset(FrameView fv) {
     if (gi == 0) {
         FrameCounters* c = fv.counters;
         c->cmd_count = 0; c->vis_count = 0; c->vis_mask_count = 0; c->deferred_count = 0;
-        c->setup_count = 0; c->mid_count = 0; c->bin_total = 0;
+        c->setup_count = 0; c->bin_total = 0;
     }
+    if (gi < kMidSegments) fv.counters->mid_seg[gi * 32u] = 0u;
 }
 
 __global__ __launch_bounds__(256) void k_clear(unsigned long long* vis, size_t n, FrameCounters* counters, uint32_t* tile_count,
@@ -1223,7 +1231,8 @@ __global__ __launch_bounds__(256) void k_clear(unsigned long long* vis, size_t n
     } else if (i < n) {
         vis[i] = RDR_VIS_CLEAR;
     }
-    if (blockIdx.x == 0 && threadIdx.x < sizeof(FrameCounters) / 4) reinterpret_cast<uint32_t*>(counters)[threadIdx.x] = 0u;
+    if (blockIdx.x == 0)
+        for (uint32_t w = threadIdx.x; w < sizeof(FrameCounters) / 4; w += blockDim.x) reinterpret_cast<uint32_t*>(counters)[w] = 0u;
 }
 
 // Packed key -> the reference's visibility-buffer texel

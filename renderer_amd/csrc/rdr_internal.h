@@ -101,12 +101,18 @@ struct FrameCounters {
     uint32_t bin_total;       // tile-bin entries needed this frame
     uint32_t bin_overflow;
     uint32_t vis_mask_count;  // alpha-masked meshlets, stored from the back of `visible`
-    uint32_t mid_count;       // SetupTri records queued for k_mid_raster
+    uint32_t _pad_mid;
     uint32_t mid_overflow;
     uint32_t _pad0[3];
     unsigned long long _pad1[16];
+    // SetupTri records queued for k_mid_raster, per segment of the queue.  Every wave of k_raster
+    // reserves its slots with an atomic that returns a value, and same-address atomics serialise
+    // (about 10 ns each): the queue is cut into segments with counters 128 bytes apart (word
+    // s * 32 counts segment s) and a workgroup always uses segment blockIdx % kMidSegments.
+    uint32_t mid_seg[32 * 32];
 };
-static_assert(sizeof(FrameCounters) == 192, "FrameCounters layout");
+constexpr uint32_t kMidSegments = 32;
+static_assert(sizeof(FrameCounters) == 192 + 4096, "FrameCounters layout");
 
 struct GpuImage {
     uint32_t width, height, mip_count, format;

@@ -307,11 +307,14 @@ def field_transforms(n_instances, seed=42, stream=54):
     return mat4_trs_batch(np.stack([x, np.zeros_like(x), z], -1), quat, scale[:, None])
 
 
-def make_field(n_instances=1250, subdivisions=5, lods=1, alpha_fraction=0.0, with_env=True, seed=42):
-    """Field-S (1 250 instances, 25.6 M triangles) / Field-XL (50 000, 1.02 G triangles)."""
+def make_field(n_instances=1250, subdivisions=5, lods=1, alpha_fraction=0.0, with_env=True, seed=42, prepared=False):
+    """Field-S (1 250 instances, 25.6 M triangles) / Field-XL (50 000, 1.02 G triangles).
+    ``prepared``: run the sphere through the library's mesh preparation (cache-ordered meshlets,
+    simplified LOD chain of up to ``lods`` levels) instead of the plain index-order meshlets over
+    the coarser subdivision levels."""
     sc = Scene()
-    verts, lod_idx, errs = icosphere(subdivisions, lods)
-    mesh = sc.append_mesh(verts, lod_idx, errs)
+    verts, lod_idx, errs = icosphere(subdivisions, 1 if prepared else lods)
+    mesh = sc.append_mesh_auto(verts, lod_idx[0], lods) if prepared else sc.append_mesh(verts, lod_idx, errs)
     sc.add_material()  # Material::default()
     xf = field_transforms(n_instances, seed)
     if alpha_fraction > 0:
