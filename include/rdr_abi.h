@@ -253,6 +253,8 @@ typedef struct rdr_stats {
     uint64_t pixels_covered;      /* filled by rdr_shade */
     uint64_t vertices_transformed;/* vertices of visible meshlets */
     uint64_t frames_timed;        /* frames kernel_ms is averaged over (time_kernels = 1) */
+    uint64_t bin_entries;         /* tile path: (triangle, 64x64 tile) pairs binned in the last frame */
+    uint64_t bin_max;             /* tile path: entries of the fullest tile */
 } rdr_stats;
 
 typedef struct rdr_renderer rdr_renderer;

@@ -208,6 +208,8 @@ class Stats(C.Structure):
         ("pixels_covered", C.c_uint64),
         ("vertices_transformed", C.c_uint64),
         ("frames_timed", C.c_uint64),
+        ("bin_entries", C.c_uint64),
+        ("bin_max", C.c_uint64),
     ]
 
     def as_dict(self):

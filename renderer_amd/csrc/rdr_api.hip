@@ -738,6 +738,10 @@ int rdr_get_stats(rdr_renderer* r, rdr_stats* out) {
         for (uint32_t b = 0; b < g.mid_blocks; ++b) st.fragments += slots[g.slot_mid + b];
         for (uint32_t b = 0; b < g.deferred_blocks; ++b) st.fragments += slots[g.slot_deferred + b];
         if (r->shaded) st.pixels_covered = fc.pixel_count;
+        st.bin_entries = fc.bin_total;
+        std::vector<uint32_t> bins((size_t)fv.tiles_x * fv.tiles_y);
+        RDR_HIP(hipMemcpy(bins.data(), fv.tile_count, bins.size() * 4, hipMemcpyDeviceToHost));
+        for (uint32_t n : bins) st.bin_max = std::max<uint64_t>(st.bin_max, n);
     }
     if (r->cfg.time_kernels && r->frames_started) {
         // events 0..5 bracket clear, draw cull, meshlet cull, raster, deferred; 6..9 bracket classification, shadow and shading.

@@ -667,7 +667,7 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
                             SetupMask mk;
                             make_setup(fv, s0, s1, s2, cull_front, t, mk);
                             t.id = (vm.instance << 7) | ti; t.draw_id = vm.draw_id;
-                            t.masked = (MASK && at.has_tex) ? 1u : 0u;
+                            t.masked = (MASK ? 2u : 0u) | ((MASK && at.has_tex) ? 1u : 0u);
                             fv.mid[slot] = t;
                             if (MASK && at.has_tex) fv.mid_mask[slot] = mk;
                         } else {
@@ -751,10 +751,9 @@ __global__ __launch_bounds__(256) void k_mid_raster(SceneView sv, FrameView fv) 
         ts.inv_area = t.inv_area; ts.dz1 = t.dz1; ts.dz2 = t.dz2;
         ts.px0 = t.px0; ts.py0 = t.py0; ts.px1 = t.px1; ts.py1 = t.py1;
         ts.valid = true;
-        const rdr_mesh_draw d = sv.draws[t.draw_id];
-        if (d.alpha_mode == 1u) {
-            const AlphaTest at = make_alpha_test(sv, d);
-            if (t.masked) {
+        if (t.masked & 2u) { // alpha-tested draw (the record says so: no dependent load for the opaque majority)
+            const AlphaTest at = make_alpha_test(sv, sv.draws[t.draw_id]);
+            if (t.masked & 1u) {
                 const SetupMask* mk = &fv.mid_mask[r];
                 SnapVert* vs[3] = {&ts.v0, &ts.v1, &ts.v2};
 #pragma unroll
@@ -847,6 +846,13 @@ RDR_DEV EdgeEq make_edge(int32_t Xa, int32_t Ya, int32_t Xb, int32_t Yb, int px,
     return q;
 }
 
+// (float)v for an edge-function value, correctly rounded like the plain conversion: below 2^53
+// in magnitude (twice the area of any triangle inside the guard band is) the value is exact in
+// a double, assembled from its two halves, and the double rounds to float once.
+RDR_DEV float edge_to_float(long long v) {
+    return (float)fma((double)(int)(v >> 32), 4294967296.0, (double)(uint32_t)v);
+}
+
 // Largest value of the edge function over the pixel box [0,w] x [0,h] from the reference pixel.
 RDR_DEV long long edge_max(const EdgeEq& q, int w, int h) {
     return q.e + (q.ax > 0 ? q.ax * w : 0) + (q.by > 0 ? q.by * h : 0);
@@ -875,7 +881,7 @@ __global__ __launch_bounds__(256) void k_tile_setup(SceneView sv, FrameView fv) 
         const uint32_t di = base_i + lane;
         ClipVert poly[10], tmp[10];
         int n = 0;
-        bool cull_front = true, masked = false;
+        bool cull_front = true, masked = false, alpha_draw = false;
         uint32_t id = 0, draw_id = 0;
         if (di < count) {
             const DeferredTriangle* dt = &fv.deferred[di];
@@ -883,6 +889,7 @@ __global__ __launch_bounds__(256) void k_tile_setup(SceneView sv, FrameView fv) 
             id = dt->id;
             const rdr_mesh_draw d = sv.draws[draw_id];
             cull_front = d.alpha_mode == 0u;
+            alpha_draw = d.alpha_mode == 1u;
             const AlphaTest at = make_alpha_test(sv, d);
             masked = at.enabled && at.has_tex;
             n = 3;
@@ -938,7 +945,7 @@ __global__ __launch_bounds__(256) void k_tile_setup(SceneView sv, FrameView fv) 
                 atomicAdd(&fv.counters->setup_overflow, 1u);
                 continue;
             }
-            t.id = id; t.draw_id = draw_id; t.masked = masked ? 1u : 0u;
+            t.id = id; t.draw_id = draw_id; t.masked = (masked ? 1u : 0u) | (alpha_draw ? 2u : 0u);
             fv.setup[slot] = t;
             if (masked) fv.setup_mask[slot] = mk;
         }
@@ -1036,8 +1043,12 @@ __global__ __launch_bounds__(256) void k_tile_raster(SceneView sv, FrameView fv)
         const int bx0 = tile_x0 + (int)(threadIdx.x & 15u) * 4, by0 = tile_y0 + (int)(threadIdx.x >> 4) * 4;
         const bool block_on_screen = bx0 < (int)fv.width && by0 < (int)fv.height;
         unsigned long long keys[16];
+        uint32_t on_screen = 0; // bit j * 4 + i: pixel (bx0 + i, by0 + j) exists
 #pragma unroll
-        for (int k = 0; k < 16; ++k) keys[k] = RDR_VIS_CLEAR;
+        for (int k = 0; k < 16; ++k) {
+            keys[k] = RDR_VIS_CLEAR;
+            on_screen |= (bx0 + (k & 3) < (int)fv.width && by0 + (k >> 2) < (int)fv.height) ? (1u << k) : 0u;
+        }
 
         for (uint32_t b0 = 0; b0 < n; b0 += kTileBatch) {
             const uint32_t nb = min((uint32_t)kTileBatch, n - b0);
@@ -1059,15 +1070,29 @@ __global__ __launch_bounds__(256) void k_tile_raster(SceneView sv, FrameView fv)
                 const EdgeEq e12 = make_edge(t.X1, t.Y1, t.X2, t.Y2, bx0, by0); // weight of v0
                 const EdgeEq e20 = make_edge(t.X2, t.Y2, t.X0, t.Y0, bx0, by0); // weight of v1
                 if (edge_max(e01, 3, 3) + e01.bias < 0 || edge_max(e12, 3, 3) + e12.bias < 0 || edge_max(e20, 3, 3) + e20.bias < 0) continue;
-                AlphaTest at;
-                at.enabled = false;
-                const SetupMask* mk = nullptr;
-                if (sv.draws[t.draw_id].alpha_mode == 1u) {
-                    at = make_alpha_test(sv, sv.draws[t.draw_id]);
-                    if (t.masked) mk = &fv.setup_mask[batch_index[k]];
-                }
                 const float z0 = t.z0, dz1 = t.dz1, dz2 = t.dz2, inv_area = t.inv_area;
                 const uint32_t id = t.id;
+                if (!(t.masked & 2u)) {
+                    // opaque: branch-free over the 16 pixels; the depth is evaluated everywhere and kept where covered
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const long long v01 = e01.e + e01.ax * i + e01.by * j;
+                            const long long v12 = e12.e + e12.ax * i + e12.by * j;
+                            const long long v20 = e20.e + e20.ax * i + e20.by * j;
+                            const bool in = (((v01 + e01.bias) | (v12 + e12.bias) | (v20 + e20.bias)) >= 0) & ((on_screen >> (j * 4 + i)) & 1u);
+                            const float l1 = edge_to_float(v20) * inv_area, l2 = edge_to_float(v01) * inv_area;
+                            const float z = clampf(fmaf(l2, dz2, fmaf(l1, dz1, z0)), 0.0f, 1.0f);
+                            const unsigned long long key = ((unsigned long long)(0x7FFFFFFFu - __float_as_uint(z)) << 32) | (unsigned long long)id;
+                            keys[j * 4 + i] = (in && key < keys[j * 4 + i]) ? key : keys[j * 4 + i];
+                            frags += in ? 1u : 0u;
+                        }
+                    }
+                    continue;
+                }
+                const AlphaTest at = make_alpha_test(sv, sv.draws[t.draw_id]);
+                const SetupMask* mk = (t.masked & 1u) ? &fv.setup_mask[batch_index[k]] : nullptr;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -1076,7 +1101,10 @@ __global__ __launch_bounds__(256) void k_tile_raster(SceneView sv, FrameView fv)
                         const long long v12 = e12.e + e12.ax * i + e12.by * j;
                         const long long v20 = e20.e + e20.ax * i + e20.by * j;
                         if (((v01 + e01.bias) | (v12 + e12.bias) | (v20 + e20.bias)) < 0) continue;
-                        if (bx0 + i >= (int)fv.width || by0 + j >= (int)fv.height) continue;
+                        if (!((on_screen >> (j * 4 + i)) & 1u)) continue;
+                        const float l1 = edge_to_float(v20) * inv_area, l2 = edge_to_float(v01) * inv_area;
+                        const float z = clampf(fmaf(l2, dz2, fmaf(l1, dz1, z0)), 0.0f, 1.0f);
+                        const unsigned long long key = ((unsigned long long)(0x7FFFFFFFu - __float_as_uint(z)) << 32) | (unsigned long long)id;
                         if (at.enabled) {
                             float alpha = 1.0f;
                             if (at.has_tex && mk) {
@@ -1097,9 +1125,6 @@ __global__ __launch_bounds__(256) void k_tile_raster(SceneView sv, FrameView fv)
                             alpha = alpha * at.factor_a;
                             if (alpha < at.cutoff) continue;
                         }
-                        const float l1 = (float)v20 * inv_area, l2 = (float)v01 * inv_area;
-                        const float z = clampf(fmaf(l2, dz2, fmaf(l1, dz1, z0)), 0.0f, 1.0f);
-                        const unsigned long long key = ((unsigned long long)(0x7FFFFFFFu - __float_as_uint(z)) << 32) | (unsigned long long)id;
                         keys[j * 4 + i] = min(keys[j * 4 + i], key);
                         frags++;
                     }

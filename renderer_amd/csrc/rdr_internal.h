@@ -77,7 +77,7 @@ struct SetupTri {
     uint32_t id;
     uint32_t draw_id;
     uint16_t px0, py0, px1, py1; // covered pixel box, clamped to the screen
-    uint32_t masked;             // alpha-tested draw with a texture: SetupMask holds uv
+    uint32_t masked;             // bit 0: SetupMask holds uv (alpha-tested draw with a texture); bit 1: alpha-tested draw
     uint32_t _pad;
 };
 static_assert(sizeof(SetupTri) == 64, "SetupTri layout");
