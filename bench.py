@@ -64,12 +64,12 @@ def secondary_series(W, H, frames, instances, subdivisions):
     import torch
     from renderer_amd import Renderer, RendererConfig, synth
     cases = [
-        ("field, lod on (3 levels)", lambda: synth.make_field(instances, subdivisions, lods=3, with_env=True),
+        ("field, lod on (simplified chain of up to 8 levels)", lambda: synth.make_field(instances, subdivisions, lods=8, with_env=True, prepared=True),
          RendererConfig(lod_enabled=True, cull_enabled=False, collect_stats=True)),
-        ("field, two-phase occlusion culling on", lambda: synth.make_field(instances, subdivisions, lods=1, with_env=True),
+        ("field, two-phase occlusion culling on", lambda: synth.make_field(instances, subdivisions, lods=1, with_env=True, prepared=True),
          RendererConfig(lod_enabled=False, cull_enabled=True, collect_stats=True)),
         ("field, 50% of draws alpha-masked (checkerboard albedo, cutoff 0.5)",
-         lambda: synth.make_field(instances, subdivisions, lods=1, alpha_fraction=0.5, with_env=True),
+         lambda: synth.make_field(instances, subdivisions, lods=1, alpha_fraction=0.5, with_env=True, prepared=True),
          RendererConfig(lod_enabled=False, cull_enabled=False, collect_stats=True)),
         ("atrium (interior stand-in for Sponza: every pixel covered, textured, large clipped triangles), skybox on",
          lambda: synth.make_atrium(columns=10, spheres=60, sphere_subdiv=5),
@@ -96,7 +96,7 @@ def secondary_series(W, H, frames, instances, subdivisions):
         r.close()
     # throughput with two frames in flight, as the reference's frame loop keeps up to three
     # (renderer/src/renderer.rs:919-922): two renderers take turns, each on its own stream
-    scene = synth.make_field(instances, subdivisions, lods=1, with_env=True)
+    scene = synth.make_field(instances, subdivisions, lods=1, with_env=True, prepared=True)
     conf = RendererConfig(lod_enabled=False, cull_enabled=False, collect_stats=True)
     pair = [Renderer(W, H, conf), Renderer(W, H, conf)]
     for r in pair:
@@ -174,7 +174,8 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     W, H = args.width, args.height
-    scene = synth.make_field(args.instances * world, args.subdivisions, lods=1, with_env=True)
+    # the sphere goes through the library's mesh preparation, as every mesh of the reference goes through append_mesh
+    scene = synth.make_field(args.instances * world, args.subdivisions, lods=1, with_env=True, prepared=True)
     tris_per_frame = scene.triangle_count()
     # occlusion culling (cull_enabled) never changes the image; on this scene nothing hides behind anything, so the
     # second phase and the depth pyramid would only cost time (series "occlusion culling on" below)
@@ -256,7 +257,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"field: {args.instances} instances/GPU x icosphere-{args.subdivisions} "
-                            f"({tris_per_frame / 1e6:.1f} Mtri submitted per frame), {W}x{H}, lod off, occlusion culling off; "
+                            f"({tris_per_frame / 1e6:.1f} Mtri submitted per frame, meshlets from the library's mesh preparation), "
+                            f"{W}x{H}, lod off, occlusion culling off; "
                             "stand-in for the Sponza/Bistro 4K configs (assets not shipped)",
                 "instances": args.instances * world, "width": W, "height": H,
                 "parallelism": "single GPU" if frame is None else

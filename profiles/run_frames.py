@@ -9,10 +9,10 @@ frames = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 scene_name = sys.argv[2] if len(sys.argv) > 2 else "field"
 w, h = 3840, 2160
 if scene_name == "field":  # exactly bench.py's single-GPU workload
-    scene = synth.make_field(1250, 5, lods=1, with_env=True)
+    scene = synth.make_field(1250, 5, lods=1, with_env=True, prepared=True)
     conf = RendererConfig(lod_enabled=False, cull_enabled=False, collect_stats=True, time_kernels=True)
 elif scene_name == "lodfield":  # the field with LOD selection on: coarse levels, mid-size triangles dominate
-    scene = synth.make_field(1250, 5, lods=4, with_env=True)
+    scene = synth.make_field(1250, 5, lods=8, with_env=True, prepared=True)
     conf = RendererConfig(lod_enabled=True, cull_enabled=False, collect_stats=True, time_kernels=True)
 else:
     scene = synth.make_atrium(columns=10, spheres=60, sphere_subdiv=5)
