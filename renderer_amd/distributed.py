@@ -65,7 +65,10 @@ def gather_rows(color, rank, world):
     lo, hi = bounds[rank]
     if len(sizes) == 1 and dist.get_backend() == "nccl":
         # equal strips: this rank's rows already sit at their offset of the output buffer (RCCL's in-place form)
-        dist.all_gather_into_tensor(color.view(-1), color[lo:hi].reshape(-1))
+        try:
+            dist.all_gather_into_tensor(color.view(-1), color[lo:hi].reshape(-1))
+        except (RuntimeError, ValueError):  # argument check refused the aliasing: same on every rank
+            dist.all_gather_into_tensor(color.view(-1), color[lo:hi].reshape(-1).clone())
     elif _host_staged(color):
         parts = [torch.empty((b - a,) + tuple(color.shape[1:]), dtype=color.dtype) for a, b in bounds]
         dist.all_gather(parts, color[lo:hi].cpu())
@@ -96,7 +99,13 @@ class SortLastFrame:
     def step(self, camera=None, sun=None):
         self.r.render_visbuffer(camera, sun)
         if self.composite == "reduce_scatter":
-            composite_min_rows(self.vis, self.height, self.rank, self.world)
+            try:
+                composite_min_rows(self.vis, self.height, self.rank, self.world)
+            except (RuntimeError, ValueError):
+                # a backend build that refuses the in-place form raises while checking its arguments, on
+                # every rank alike and before anything is enqueued: all ranks switch to the all-reduce
+                self.composite = "all_reduce"
+                composite_min(self.vis)
         else:
             composite_min(self.vis)
         self.r.shade()
@@ -120,8 +129,12 @@ class SortLastPipeline:
             vis = torch.as_tensor(r.visbuffer_device_array(), device="cuda")
             color = torch.as_tensor(r.color_device_array(), device="cuda")
             self.slots.append((SortLastFrame(r, n_instances, height, rank, world, vis, color, composite), stream))
-        self.composite = self.slots[0][0].composite
         self.issued = 0
+
+    @property
+    def composite(self):
+        """The exchange step in use (a refused reduce-scatter falls back to the all-reduce)."""
+        return self.slots[0][0].composite
 
     def step(self, camera=None, sun=None):
         """Issue one frame; returns its slot's ``SortLastFrame`` (``.color`` is valid once
