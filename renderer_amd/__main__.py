@@ -18,7 +18,7 @@ from .scene_bin import load_scene_bin, save_scene_bin
 
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="python -m renderer_amd", description=__doc__.split("\n\n")[0])
-    ap.add_argument("scene", help="path of a scene.bin / .gltf / .glb, or synth:field / synth:atrium")
+    ap.add_argument("scene", help="path of a scene.bin / .gltf / .glb / .obj (several .obj separated by commas), or synth:field / synth:atrium")
     ap.add_argument("--size", type=int, nargs=2, default=(1280, 720), metavar=("W", "H"))
     ap.add_argument("--camera", type=float, nargs=6, metavar=("PX", "PY", "PZ", "DX", "DY", "DZ"))
     ap.add_argument("--sun", type=float, nargs=3)
@@ -38,6 +38,9 @@ def main(argv=None):
     elif args.scene.lower().endswith((".gltf", ".glb")):
         from .gltf import load_gltf
         scene = load_gltf(args.scene, env=synth.default_env())  # IBL inputs: the synthetic sky (see renderer_amd.bake for real ones)
+    elif args.scene.lower().endswith(".obj") or ".obj," in args.scene.lower():
+        from .obj import load_obj
+        scene = load_obj(args.scene, env=synth.default_env())
     else:
         scene = load_scene_bin(args.scene)
     if args.camera:
