@@ -22,6 +22,8 @@ def main(argv=None):
     ap.add_argument("--size", type=int, nargs=2, default=(1280, 720), metavar=("W", "H"))
     ap.add_argument("--camera", type=float, nargs=6, metavar=("PX", "PY", "PZ", "DX", "DY", "DZ"))
     ap.add_argument("--sun", type=float, nargs=3)
+    ap.add_argument("--env", help="environment JSON naming five KTX2 files (skybox, brdf_lut, lambertian, ggx, charlie), "
+                                  "as the reference's second command-line argument; default: a synthetic sky")
     ap.add_argument("--lod", action="store_true", help="RendererConfig.lod_enabled")
     ap.add_argument("--skybox", action="store_true", help="run the skybox pass on uncovered pixels")
     ap.add_argument("--frames", type=int, default=1, help="render this many frames and report the mean time")
@@ -43,6 +45,9 @@ def main(argv=None):
         scene = load_obj(args.scene, env=synth.default_env())
     else:
         scene = load_scene_bin(args.scene)
+    if args.env:
+        from .ktx2 import load_env_json
+        scene.env = load_env_json(args.env)
     if args.camera:
         scene.camera = Camera(tuple(args.camera[:3]), tuple(args.camera[3:]))
     if args.sun:
