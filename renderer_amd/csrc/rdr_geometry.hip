@@ -518,6 +518,7 @@ struct MeshletLds {
     float sx[64], sy[64];                 // the mesh shader's y-up screen position
     int32_t X[64], Y[64];                 // snapped framebuffer position
     uint32_t clip[64];                    // vertex is outside the near plane / guard band
+    uint32_t queue[128];                  // triangles that survived the cull tests: vertex bytes | index << 24
 };
 
 // MASK = false: meshlets of opaque draws (front of the visible list); MASK = true:
@@ -584,11 +585,46 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
         if (has_next && lane < (vm_next.counts & 0xFFFFu)) // in flight during the triangle phase
             vi_next = sv.meshlet_vertices[vm_next.vertex_offset + lane] + vm_next.mesh_vertex_offset;
 
+        // Triangle phase 1: the mesh shader's cull tests, two triangles per lane; the survivors (about
+        // four in ten on a closed mesh) are packed into an LDS queue so that phase 2 runs on full lanes.
+        uint32_t n_queued = 0;
         for (uint32_t t0 = 0; t0 < m.triangle_count; t0 += 64) {
             const uint32_t ti = t0 + lane;
+            bool keep = false;
+            uint32_t packed = 0;
+            if (ti < m.triangle_count) {
+                uint32_t tri_bytes = first_tri;
+                if (t0) {
+                    const uint8_t* tp = sv.meshlet_triangles + m.triangle_offset + ti * 3;
+                    tri_bytes = (uint32_t)tp[0] | ((uint32_t)tp[1] << 8) | ((uint32_t)tp[2] << 16);
+                }
+                const uint32_t ia = tri_bytes & 255u, ib = (tri_bytes >> 8) & 255u, ic = tri_bytes >> 16;
+                st_tested++;
+                const float ax = lds.sx[ia], ay = lds.sy[ia], bx = lds.sx[ib], by = lds.sy[ib];
+                const float cx = lds.sx[ic], cy = lds.sy[ic];
+                const float ebax = bx - ax, ebay = by - ay, ecax = cx - ax, ecay = cy - ay;
+                bool culled = ebax * ecay <= ebay * ecax;
+                const float bminx = fminf(ax, fminf(bx, cx)), bminy = fminf(ay, fminf(by, cy));
+                const float bmaxx = fmaxf(ax, fmaxf(bx, cx)), bmaxy = fmaxf(ay, fmaxf(by, cy));
+                const float sbprec = 1.0f / 256.0f;
+                culled = culled || (rintf(bminx - sbprec) == rintf(bmaxx) || rintf(bminy) == rintf(bmaxy + sbprec));
+                culled = culled && (lds.cw[ia] > 0.0f && lds.cw[ib] > 0.0f && lds.cw[ic] > 0.0f);
+                keep = !culled;
+                packed = tri_bytes | (ti << 24);
+            }
+            const unsigned long long km = __ballot(keep);
+            if (keep) {
+                st_raster++;
+                lds.queue[n_queued + ballot_rank(km)] = packed;
+            }
+            n_queued += (uint32_t)__popcll(km);
+        }
+        __syncthreads(); // the queue is complete
+        // Triangle phase 2: set-up and scan of the queued triangles, one per lane
+        for (uint32_t q0 = 0; q0 < n_queued; q0 += 64) {
             bool defer = false; // clipped, large or pixel-heavy triangles go to the tile path
             bool mid = false;   // too many pixels for one lane: queued for k_mid_raster
-            uint32_t ia = 0, ib = 0, ic = 0;
+            uint32_t ia = 0, ib = 0, ic = 0, ti = 0;
             // snapped vertices of the triangle with meshlet-local vertices (a, b, c), from the wave's LDS
             auto load_snap = [&](uint32_t a, uint32_t b, uint32_t c, SnapVert& s0, SnapVert& s1, SnapVert& s2) {
                 s0.X = lds.X[a]; s0.Y = lds.Y[a]; s0.z = lds.z[a];
@@ -609,42 +645,25 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
                     s2.u0 = vc->uv[0]; s2.v0 = vc->uv[1]; s2.u1 = vc->uv[2]; s2.v1 = vc->uv[3];
                 }
             };
-            if (ti < m.triangle_count) {
-                uint32_t tri_bytes = first_tri;
-                if (t0) {
-                    const uint8_t* tp = sv.meshlet_triangles + m.triangle_offset + ti * 3;
-                    tri_bytes = (uint32_t)tp[0] | ((uint32_t)tp[1] << 8) | ((uint32_t)tp[2] << 16);
-                }
-                ia = tri_bytes & 255u; ib = (tri_bytes >> 8) & 255u; ic = tri_bytes >> 16;
-                st_tested++;
-                const float ax = lds.sx[ia], ay = lds.sy[ia], bx = lds.sx[ib], by = lds.sy[ib];
-                const float cx = lds.sx[ic], cy = lds.sy[ic];
-                const float ebax = bx - ax, ebay = by - ay, ecax = cx - ax, ecay = cy - ay;
-                bool culled = ebax * ecay <= ebay * ecax;
-                const float bminx = fminf(ax, fminf(bx, cx)), bminy = fminf(ay, fminf(by, cy));
-                const float bmaxx = fmaxf(ax, fmaxf(bx, cx)), bmaxy = fmaxf(ay, fmaxf(by, cy));
-                const float sbprec = 1.0f / 256.0f;
-                culled = culled || (rintf(bminx - sbprec) == rintf(bmaxx) || rintf(bminy) == rintf(bmaxy + sbprec));
-                culled = culled && (lds.cw[ia] > 0.0f && lds.cw[ib] > 0.0f && lds.cw[ic] > 0.0f);
-                if (!culled) {
-                    st_raster++;
-                    defer = (lds.clip[ia] | lds.clip[ib] | lds.clip[ic]) != 0u;
+            if (q0 + lane < n_queued) {
+                const uint32_t packed = lds.queue[q0 + lane];
+                ia = packed & 255u; ib = (packed >> 8) & 255u; ic = (packed >> 16) & 255u; ti = packed >> 24;
+                defer = (lds.clip[ia] | lds.clip[ib] | lds.clip[ic]) != 0u;
+                if (!defer) {
+                    const int32_t X0 = lds.X[ia], X1 = lds.X[ib], X2 = lds.X[ic];
+                    const int32_t Y0 = lds.Y[ia], Y1 = lds.Y[ib], Y2 = lds.Y[ic];
+                    const int32_t ex = max(X0, max(X1, X2)) - min(X0, min(X1, X2));
+                    const int32_t ey = max(Y0, max(Y1, Y2)) - min(Y0, min(Y1, Y2));
+                    defer = ex > kSmallExtent || ey > kSmallExtent;
                     if (!defer) {
-                        const int32_t X0 = lds.X[ia], X1 = lds.X[ib], X2 = lds.X[ic];
-                        const int32_t Y0 = lds.Y[ia], Y1 = lds.Y[ib], Y2 = lds.Y[ic];
-                        const int32_t ex = max(X0, max(X1, X2)) - min(X0, min(X1, X2));
-                        const int32_t ey = max(Y0, max(Y1, Y2)) - min(Y0, min(Y1, Y2));
-                        defer = ex > kSmallExtent || ey > kSmallExtent;
-                        if (!defer) {
-                            SnapVert s0, s1, s2;
-                            load_snap(ia, ib, ic, s0, s1, s2);
-                            const TriSetup<int32_t> ts = setup_triangle<int32_t>(fv, s0, s1, s2, cull_front);
-                            if (ts.valid) {
-                                const int npx = (ts.px1 - ts.px0 + 1) * (ts.py1 - ts.py0 + 1);
-                                defer = npx > (int)fv.mid_max_pixels;
-                                mid = !defer && npx > (int)fv.lane_max_pixels;
-                                if (!defer && !mid) st_frags += scan_lane<int32_t, MASK>(sv, fv, ts, at, (vm.instance << 7) | ti);
-                            }
+                        SnapVert s0, s1, s2;
+                        load_snap(ia, ib, ic, s0, s1, s2);
+                        const TriSetup<int32_t> ts = setup_triangle<int32_t>(fv, s0, s1, s2, cull_front);
+                        if (ts.valid) {
+                            const int npx = (ts.px1 - ts.px0 + 1) * (ts.py1 - ts.py0 + 1);
+                            defer = npx > (int)fv.mid_max_pixels;
+                            mid = !defer && npx > (int)fv.lane_max_pixels;
+                            if (!defer && !mid) st_frags += scan_lane<int32_t, MASK>(sv, fv, ts, at, (vm.instance << 7) | ti);
                         }
                     }
                 }
