@@ -120,3 +120,73 @@ def test_baked_environment_renders(oracle):
     g.set_scene(sc)
     g.render()
     assert np.abs(g.read_color().astype(np.int32) - ref.astype(np.int32)).max() <= 2
+
+
+def _write_hdr(path, img, rle):
+    """Radiance RGBE writer for the reader's test (shared exponent per pixel)."""
+    h, w = img.shape[:2]
+    m = img[..., :3].max(-1)
+    e = np.where(m > 1e-32, np.floor(np.log2(np.maximum(m, 1e-38))) + 1, 0).astype(np.int32)
+    mant = np.where(m[..., None] > 1e-32, img[..., :3] / np.ldexp(1.0, e)[..., None] * 256.0, 0.0)
+    rgbe = np.concatenate([np.clip(mant, 0, 255).astype(np.uint8), np.where(m > 1e-32, e + 128, 0).astype(np.uint8)[..., None]], -1)
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w))
+        for y in range(h):
+            if not rle:
+                f.write(rgbe[y].tobytes())
+                continue
+            f.write(bytes([2, 2, w >> 8, w & 255]))
+            for c in range(4):
+                row, x = rgbe[y, :, c], 0
+                while x < w:  # runs of equal bytes as runs, the rest as literals of up to 128
+                    n = 1
+                    while x + n < w and n < 127 and row[x + n] == row[x]:
+                        n += 1
+                    if n >= 3:
+                        f.write(bytes([128 + n, row[x]]))
+                    else:
+                        n = 1
+                        while x + n < w and n < 128 and not (x + n + 2 < w and row[x + n] == row[x + n + 1] == row[x + n + 2]):
+                            n += 1
+                        f.write(bytes([n]) + row[x:x + n].tobytes())
+                    x += n
+    return rgbe
+
+
+@pytest.mark.parametrize("rle", [False, True])
+def test_radiance_hdr_reader(tmp_path, rle):
+    from renderer_amd.bake import read_radiance_hdr
+    rng = np.random.default_rng(3)
+    img = (rng.random((6, 40, 3)) * np.array([4.0, 1.0, 0.01])).astype(np.float32)
+    img[2, 5:30] = img[2, 5]          # a long run
+    img[4] = 0.0                       # black: exponent byte 0
+    rgbe = _write_hdr(tmp_path / "s.hdr", img, rle)
+    got = read_radiance_hdr(tmp_path / "s.hdr")
+    want = rgbe[..., :3].astype(np.float32) * np.where(rgbe[..., 3:] > 0, np.ldexp(1.0, rgbe[..., 3:].astype(np.int32) - 136), 0.0)
+    assert got.shape == (6, 40, 4) and np.array_equal(got[..., :3], want.astype(np.float32)) and (got[..., 3] == 1).all()
+    assert np.abs(got[..., :3] - img).max() <= np.abs(img).max() / 128
+
+
+def test_equirect_to_cubemap_follows_the_reference_mapping():
+    """Spot values against the reference's formulas written out by hand (bake/src/cubemaps.rs:9-118):
+    cubemap face 4 (+Z) is the centre of the vertical cross, i.e. cross face 2 = direction
+    (1, a - 1, 1 - b): its centre looks along +x, which the equirect mapping puts at u = width / 2
+    (theta = 0), v = height / 2 (phi = 0)."""
+    from renderer_amd.bake import equirect_to_cubemap
+    w, h = 64, 32
+    u, v = np.meshgrid(np.arange(w), np.arange(h))
+    img = np.stack([u / w, v / h, np.full_like(u, 0.5, dtype=float), np.ones_like(u, dtype=float)], -1).astype(np.float32)
+    cm = equirect_to_cubemap(img)
+    fs = w // 4
+    assert len(cm.mips) == int(np.log2(fs)) and cm.mips[0].shape == (6, fs, fs, 4) and cm.mips[0].dtype == np.uint8
+    assert [m.shape[1] for m in cm.mips] == [16, 8, 4, 2]
+    centre = cm.mips[0][4][fs // 2, fs // 2].astype(int)
+    assert abs(centre[0] - int(0.5 * 255)) <= 2 and abs(centre[1] - int(0.5 * 255)) <= 2 and centre[2] == 127 and centre[3] == 255
+    # cubemap face 2 (+Y) is the top of the cross = cross face 4 = (b - 1, a - 1, 1): straight along +z = the picture's top row
+    top = cm.mips[0][2][fs // 2, fs // 2].astype(int)
+    assert top[1] <= 4
+    # cubemap face 3 (-Y) = cross face 5 = (1 - b, a - 1, -1): the bottom row
+    assert cm.mips[0][3][fs // 2, fs // 2, 1] >= 240
+    # a constant picture gives a constant cubemap on every level, values truncated not rounded
+    flat = equirect_to_cubemap(np.full((32, 64, 4), 0.999 * 200 / 255, np.float32))
+    assert all((m[..., :3] == 199).all() for m in flat.mips)
