@@ -190,3 +190,32 @@ def test_equirect_to_cubemap_follows_the_reference_mapping():
     # a constant picture gives a constant cubemap on every level, values truncated not rounded
     flat = equirect_to_cubemap(np.full((32, 64, 4), 0.999 * 200 / 255, np.float32))
     assert all((m[..., :3] == 199).all() for m in flat.mips)
+
+
+@pytest.mark.gpu
+def test_bake_command_line_feeds_the_renderer(oracle, tmp_path):
+    """sky picture -> `python -m renderer_amd.bake` -> EnvMap JSON + KTX2 files -> loaded back -> a frame
+    rendered with it matches the oracle rendering with the same files."""
+    from renderer_amd import Renderer, RendererConfig
+    from renderer_amd.bake import main as bake_main
+    from renderer_amd.ktx2 import load_env_json
+    w, h = 128, 64
+    u, v = np.meshgrid(np.arange(w), np.arange(h))
+    sky = np.stack([0.2 + 0.6 * u / w, 0.3 + 0.5 * (1 - v / h), 0.9 - 0.5 * v / h, np.ones_like(u, dtype=float)], -1).astype(np.float32)
+    np.save(tmp_path / "sky.npy", sky)
+    assert bake_main([str(tmp_path / "sky.npy"), str(tmp_path / "env.json"), "--size", "16", "--samples", "32",
+                      "--lut-size", "16", "--lut-samples", "64"]) == 0
+    env = load_env_json(tmp_path / "env.json")
+    assert env.skybox.mips[0].shape == (6, 32, 32, 4) and env.ggx.mips[0].shape == (6, 16, 16, 4) and len(env.ggx.mips) == 4
+    sc = synth.make_atrium()
+    sc.env = env
+    conf = RendererConfig(skybox=True)
+    o = oracle.OracleRenderer(160, 90, conf)
+    o.set_scene(sc)
+    o.render_visbuffer()
+    ref = o.shade()
+    g = Renderer(160, 90, conf)
+    g.set_scene(sc)
+    g.render()
+    assert np.abs(g.read_color().astype(np.int32) - ref.astype(np.int32)).max() <= 2
+    g.close()
