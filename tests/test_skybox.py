@@ -97,3 +97,84 @@ def test_hip_skybox_matches_oracle(oracle, scene_name):
     g.shade()
     both = np.concatenate([top, g.read_color()[h // 2:]])
     assert np.array_equal(both, img)
+
+
+def _cube_face(d):
+    x, y, z = d
+    ax, ay, az = abs(x), abs(y), abs(z)
+    if ax >= ay and ax >= az:
+        return (0, -z, -y, ax) if x >= 0 else (1, z, -y, ax)
+    if ay >= az:
+        return (2, x, z, ay) if y >= 0 else (3, x, -z, ay)
+    return (4, x, -y, az) if z >= 0 else (5, -x, -y, az)
+
+
+def _cube_dir(face, a, b):
+    return [(1.0, -b, -a), (-1.0, -b, a), (a, 1.0, b), (a, -1.0, -b), (a, -b, 1.0), (-a, -b, -1.0)][face]
+
+
+def _sample_by_reprojection(faces, d):
+    """Bilinear cube sample where a tap outside the face is fetched from the texel that contains its
+    re-projected centre (float64, written independently of the integer rule the library uses).
+    Returns (rgba, touches_a_corner)."""
+    n = faces.shape[1]
+    face, sc, tc, ma = _cube_face(d)
+    x, y = 0.5 * (sc / ma + 1) * n - 0.5, 0.5 * (tc / ma + 1) * n - 0.5
+    i0, j0 = int(np.floor(x)), int(np.floor(y))
+    ax, ay = x - i0, y - j0
+    taps, corner = [], False
+    for j in (j0, j0 + 1):
+        for i in (i0, i0 + 1):
+            f, ii, jj = face, i, j
+            out_i, out_j = not 0 <= i < n, not 0 <= j < n
+            corner |= out_i and out_j
+            if out_i or out_j:
+                a, b = (i + 0.5) / n * 2 - 1, (j + 0.5) / n * 2 - 1
+                f, s2, t2, m2 = _cube_face(_cube_dir(face, a, b))
+                ii = min(max(int(np.floor(0.5 * (s2 / m2 + 1) * n)), 0), n - 1)
+                jj = min(max(int(np.floor(0.5 * (t2 / m2 + 1) * n)), 0), n - 1)
+            taps.append(faces[f, jj, ii].astype(np.float64))
+    top = taps[0] * (1 - ax) + taps[1] * ax
+    bot = taps[2] * (1 - ax) + taps[3] * ax
+    return top * (1 - ay) + bot * ay, corner
+
+
+@pytest.mark.parametrize("direction", [(1.0, 1.0, 0.05), (-1.0, 0.1, 1.0), (0.05, -1.0, -1.0), (1.0, -0.1, -1.0),
+                                       (-0.1, 1.0, 1.0), (-1.0, -1.0, 0.1)])
+def test_oracle_seamless_edges_take_the_reprojected_texel(oracle, direction):
+    """Looking at a cube edge with a small random cubemap: every sky pixel whose footprint stays clear
+    of a cube corner must equal the bilinear blend over re-projected texels."""
+    rng = np.random.default_rng(11)
+    n = 8
+    faces = rng.random((6, n, n, 4)).astype(np.float32)
+    w, h = 40, 24
+    sc = synth.make_triangle_scene([(2.0, 1.0, -49.0), (4.0, 1.0, -49.0), (3.0, 3.0, -49.0)])
+    env = synth.default_env()
+    env.skybox = Cubemap([faces])
+    sc.env = env
+    sc.camera = Camera((3.0, 2.0, 50.0), direction)
+    o = oracle.OracleRenderer(w, h, RendererConfig(skybox=True))
+    o.set_scene(sc)
+    vis = o.render_visbuffer()
+    img = o.shade().astype(np.int32)
+    vp = np.array(o.ubo.view_proj, np.float64).reshape(4, 4).T
+    inv, cam = np.linalg.inv(vp), np.array(o.ubo.camera_position, np.float64)
+    checked = crossing = 0
+    for y in range(h):
+        for x in range(w):
+            if covered(vis)[y, x]:
+                continue
+            p = inv @ np.array([2 * (x + 0.5) / w - 1, 1 - 2 * (y + 0.5) / h, 0.5, 1.0])
+            d = p[:3] / p[3] - cam
+            rgba, corner = _sample_by_reprojection(faces, d)
+            if corner:
+                continue
+            c = np.clip(rgba[:3], 0, 1)
+            srgb = np.where(c <= 0.0031308, 12.92 * c, 1.055 * c ** (1 / 2.4) - 0.055)
+            want = np.floor(np.append(srgb, rgba[3]) * 255 + 0.5)
+            assert np.abs(img[y, x] - want).max() <= 1, (x, y, img[y, x], want)
+            checked += 1
+            face, sc_, tc_, ma = _cube_face(d)
+            fx, fy = 0.5 * (sc_ / ma + 1) * n - 0.5, 0.5 * (tc_ / ma + 1) * n - 0.5
+            crossing += not (0 <= fx < n - 1 and 0 <= fy < n - 1)
+    assert checked > w * h // 2 and crossing > 20  # a good share of the footprints really cross an edge
