@@ -352,11 +352,20 @@ RDR_DEV void emit_fragment(const FrameView& fv, int px, int py, float z, uint32_
     __hip_atomic_fetch_min(p, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// (float)v for an edge-function value, correctly rounded like the plain conversion: below 2^53
+// in magnitude (twice the area of any triangle inside the guard band is) the value is exact in
+// a double, assembled from its two halves, and the double rounds to float once.
+RDR_DEV float edge_to_float(long long v) {
+    return (float)fma((double)(int)(v >> 32), 4294967296.0, (double)(uint32_t)v);
+}
+RDR_DEV float edge_value_to_float(long long v) { return edge_to_float(v); }
+RDR_DEV float edge_value_to_float(int32_t v) { return (float)v; }
+
 // Perspective-correct uv at the sample with edge values (e0, e1, e2).
 template <typename I>
 RDR_DEV void persp_uv(const SnapVert& a, const SnapVert& b, const SnapVert& c, I e0, I e1, I e2, uint32_t set,
                       float& u, float& v) {
-    const float b0 = (float)e0 * a.inv_w, b1 = (float)e1 * b.inv_w, b2 = (float)e2 * c.inv_w;
+    const float b0 = edge_value_to_float(e0) * a.inv_w, b1 = edge_value_to_float(e1) * b.inv_w, b2 = edge_value_to_float(e2) * c.inv_w;
     const float sum = (b0 + b1) + b2;
     if (set == 0u) {
         u = ((b0 * a.u0 + b1 * b.u0) + b2 * c.u0) / sum;
@@ -865,13 +874,6 @@ RDR_DEV EdgeEq make_edge(int32_t Xa, int32_t Ya, int32_t Xb, int32_t Yb, int px,
     return q;
 }
 
-// (float)v for an edge-function value, correctly rounded like the plain conversion: below 2^53
-// in magnitude (twice the area of any triangle inside the guard band is) the value is exact in
-// a double, assembled from its two halves, and the double rounds to float once.
-RDR_DEV float edge_to_float(long long v) {
-    return (float)fma((double)(int)(v >> 32), 4294967296.0, (double)(uint32_t)v);
-}
-
 // Largest value of the edge function over the pixel box [0,w] x [0,h] from the reference pixel.
 RDR_DEV long long edge_max(const EdgeEq& q, int w, int h) {
     return q.e + (q.ax > 0 ? q.ax * w : 0) + (q.by > 0 ? q.by * h : 0);
@@ -1112,6 +1114,8 @@ __global__ __launch_bounds__(256) void k_tile_raster(SceneView sv, FrameView fv)
                 }
                 const AlphaTest at = make_alpha_test(sv, sv.draws[t.draw_id]);
                 const SetupMask* mk = (t.masked & 1u) ? &fv.setup_mask[batch_index[k]] : nullptr;
+                // alpha-tested: coverage of the block first, then the texture is consulted only where it matters
+                uint32_t cov = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -1119,34 +1123,56 @@ __global__ __launch_bounds__(256) void k_tile_raster(SceneView sv, FrameView fv)
                         const long long v01 = e01.e + e01.ax * i + e01.by * j;
                         const long long v12 = e12.e + e12.ax * i + e12.by * j;
                         const long long v20 = e20.e + e20.ax * i + e20.by * j;
-                        if (((v01 + e01.bias) | (v12 + e12.bias) | (v20 + e20.bias)) < 0) continue;
-                        if (!((on_screen >> (j * 4 + i)) & 1u)) continue;
-                        const float l1 = edge_to_float(v20) * inv_area, l2 = edge_to_float(v01) * inv_area;
-                        const float z = clampf(fmaf(l2, dz2, fmaf(l1, dz1, z0)), 0.0f, 1.0f);
-                        const unsigned long long key = ((unsigned long long)(0x7FFFFFFFu - __float_as_uint(z)) << 32) | (unsigned long long)id;
+                        cov |= (((v01 + e01.bias) | (v12 + e12.bias) | (v20 + e20.bias)) >= 0) ? (1u << (j * 4 + i)) : 0u;
+                    }
+                }
+                cov &= on_screen;
+                if (cov == 0u) continue;
+                const bool textured = at.enabled && at.has_tex && mk;
+                SnapVert a{}, b{}, c{};
+                if (textured) {
+                    a.inv_w = mk->inv_w[0]; b.inv_w = mk->inv_w[1]; c.inv_w = mk->inv_w[2];
+                    a.u0 = mk->uv[0][0]; a.v0 = mk->uv[0][1]; a.u1 = mk->uv[0][2]; a.v1 = mk->uv[0][3];
+                    b.u0 = mk->uv[1][0]; b.v0 = mk->uv[1][1]; b.u1 = mk->uv[1][2]; b.v1 = mk->uv[1][3];
+                    c.u0 = mk->uv[2][0]; c.v0 = mk->uv[2][1]; c.u1 = mk->uv[2][2]; c.v1 = mk->uv[2][3];
+                }
+                // Perspective-correct uv on the block's 5 x 5 sample grid, a row at a time: a pixel's forward
+                // differences are its right and lower neighbours' own uv, so 25 evaluations serve 16 pixels.
+                auto uv_row = [&](int j, float* ru, float* rv) {
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) {
+                        float u, v;
+                        persp_uv<long long>(a, b, c, e12.e + e12.ax * i + e12.by * j, e20.e + e20.ax * i + e20.by * j,
+                                            e01.e + e01.ax * i + e01.by * j, at.uv_set, u, v);
+                        ru[i] = u * at.sx + at.ox;
+                        rv[i] = v * at.sy + at.oy;
+                    }
+                };
+                float ru[5] = {}, rv[5] = {}, nu[5] = {}, nv[5] = {};
+                if (textured) uv_row(0, ru, rv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (textured) uv_row(j + 1, nu, nv);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (!((cov >> (j * 4 + i)) & 1u)) continue;
                         if (at.enabled) {
                             float alpha = 1.0f;
-                            if (at.has_tex && mk) {
-                                SnapVert a{}, b{}, c{};
-                                a.inv_w = mk->inv_w[0]; b.inv_w = mk->inv_w[1]; c.inv_w = mk->inv_w[2];
-                                a.u0 = mk->uv[0][0]; a.v0 = mk->uv[0][1]; a.u1 = mk->uv[0][2]; a.v1 = mk->uv[0][3];
-                                b.u0 = mk->uv[1][0]; b.v0 = mk->uv[1][1]; b.u1 = mk->uv[1][2]; b.v1 = mk->uv[1][3];
-                                c.u0 = mk->uv[2][0]; c.v0 = mk->uv[2][1]; c.u1 = mk->uv[2][2]; c.v1 = mk->uv[2][3];
-                                float u, v, ux, vx, uy, vy;
-                                persp_uv<long long>(a, b, c, v12, v20, v01, at.uv_set, u, v);
-                                persp_uv<long long>(a, b, c, v12 + e12.ax, v20 + e20.ax, v01 + e01.ax, at.uv_set, ux, vx);
-                                persp_uv<long long>(a, b, c, v12 + e12.by, v20 + e20.by, v01 + e01.by, at.uv_set, uy, vy);
-                                u = u * at.sx + at.ox; v = v * at.sy + at.oy;
-                                ux = ux * at.sx + at.ox; vx = vx * at.sy + at.oy;
-                                uy = uy * at.sx + at.ox; vy = vy * at.sy + at.oy;
-                                alpha = image_sample_grad(sv.images[at.image], sv.texels, sv.srgb_lut, u, v, ux - u, vx - v, uy - u, vy - v).w;
-                            }
+                            if (textured)
+                                alpha = image_sample_grad(sv.images[at.image], sv.texels, sv.srgb_lut, ru[i], rv[i], ru[i + 1] - ru[i],
+                                                          rv[i + 1] - rv[i], nu[i] - ru[i], nv[i] - rv[i]).w;
                             alpha = alpha * at.factor_a;
                             if (alpha < at.cutoff) continue;
                         }
+                        const long long v01 = e01.e + e01.ax * i + e01.by * j, v20 = e20.e + e20.ax * i + e20.by * j;
+                        const float l1 = edge_to_float(v20) * inv_area, l2 = edge_to_float(v01) * inv_area;
+                        const float z = clampf(fmaf(l2, dz2, fmaf(l1, dz1, z0)), 0.0f, 1.0f);
+                        const unsigned long long key = ((unsigned long long)(0x7FFFFFFFu - __float_as_uint(z)) << 32) | (unsigned long long)id;
                         keys[j * 4 + i] = min(keys[j * 4 + i], key);
                         frags++;
                     }
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) { ru[i] = nu[i]; rv[i] = nv[i]; }
                 }
             }
         }
