@@ -992,16 +992,20 @@ RDR_DEV void bin_visit(const FrameView& fv, const SetupTri& t, uint32_t record, 
     }
 }
 
+constexpr uint32_t kBinChunk = 8;
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_tile_bin(FrameView fv) {
     const uint32_t lane = lane_id();
     const uint32_t count = min(fv.counters->setup_count, fv.setup_capacity);
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t base_i = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base_i < count; base_i += stride) {
+    // A wave takes kBinChunk records at a time, not 64: records that cover many tiles are walked by
+    // the whole wave one after another, and a frame usually has few records but some very wide ones
+    // (walls, floors), so small chunks spread those over many more waves.
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t base_i = wave * kBinChunk; base_i < count; base_i += n_waves * kBinChunk) {
         const uint32_t i = base_i + lane;
         uint32_t tx0 = 0, ty0 = 0, tw = 0, n_tiles = 0;
         SetupTri t;
-        if (i < count) {
+        if (lane < kBinChunk && i < count) {
             t = fv.setup[i];
             tx0 = t.px0 / kTile; ty0 = t.py0 / kTile;
             tw = t.px1 / kTile - tx0 + 1u;
