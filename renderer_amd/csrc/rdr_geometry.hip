@@ -992,7 +992,7 @@ RDR_DEV void bin_visit(const FrameView& fv, const SetupTri& t, uint32_t record, 
     }
 }
 
-constexpr uint32_t kBinChunk = 8;
+constexpr uint32_t kBinChunk = 4;
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_tile_bin(FrameView fv) {
     const uint32_t lane = lane_id();
