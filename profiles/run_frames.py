@@ -14,6 +14,9 @@ if scene_name == "field":  # exactly bench.py's single-GPU workload
 elif scene_name == "lodfield":  # the field with LOD selection on: coarse levels, mid-size triangles dominate
     scene = synth.make_field(1250, 5, lods=8, with_env=True, prepared=True)
     conf = RendererConfig(lod_enabled=True, cull_enabled=False, collect_stats=True, time_kernels=True)
+elif scene_name == "alphafield":  # half of the draws alpha-masked with a checkerboard albedo
+    scene = synth.make_field(1250, 5, lods=1, alpha_fraction=0.5, with_env=True, prepared=True)
+    conf = RendererConfig(lod_enabled=False, cull_enabled=False, collect_stats=True, time_kernels=True)
 else:
     scene = synth.make_atrium(columns=10, spheres=60, sphere_subdiv=5)
     conf = RendererConfig(cull_enabled=os.environ.get("RDR_OCCLUSION", "0") != "0", collect_stats=True, time_kernels=True)
