@@ -83,6 +83,8 @@ struct rdr_renderer {
     DeviceBuffer<float> srgb_lut;
     DeviceBuffer<uint8_t> shadow;
     DeviceBuffer<uint32_t> pixel_list;
+    DeviceBuffer<FragTri> frag_tri;
+    DeviceBuffer<uint32_t> frag_px;
     DeviceBuffer<uint32_t> stat_slots;
 
     // scene resources
@@ -333,6 +335,8 @@ FrameView make_frame_view(rdr_renderer* r) {
     fv.mid = r->mid.ptr;
     fv.mid_mask = r->mid_mask.ptr;
     fv.mid_capacity = (uint32_t)r->mid.count;
+    fv.frag_tri = r->frag_tri.ptr; fv.frag_px = r->frag_px.ptr;
+    fv.frag_tri_capacity = (uint32_t)r->frag_tri.count; fv.frag_px_capacity = (uint32_t)r->frag_px.count;
     fv.skybox = (r->cfg.skybox && r->sv.skybox.mip_count) ? 1u : 0u;
     fv.occlusion = r->occlusion ? 1u : 0u;
     fv.draw_visible = r->draw_visible.ptr;
@@ -363,13 +367,15 @@ FrameView make_frame_view(rdr_renderer* r) {
     g.raster_mask_blocks = std::max(1u, std::min(r->masked_meshlets, std::max(1u, r->resident.raster_mask)));
     g.deferred_blocks = fv.tiles_x * fv.tiles_y; // one workgroup per 64x64 tile
     g.mid_blocks = std::max(1u, r->resident.mid_raster);
+    g.frag_blocks = r->masked_meshlets ? std::max(1u, r->resident.alpha_frag) : 1u;
     g.shade_blocks_x = (r->width + 15u) / 16u;
     g.shade_blocks_y = (fv.row_hi - fv.row_lo + 15u) / 16u;
     g.slot_draw = 0;
     g.slot_cull = g.slot_draw + g.draw_blocks;
     g.slot_raster = g.slot_cull + g.cull_blocks * kCullSlots;
     g.slot_mid = g.slot_raster + (g.raster_blocks + g.raster_mask_blocks) * kRasterSlots;
-    g.slot_deferred = g.slot_mid + g.mid_blocks;
+    g.slot_frag = g.slot_mid + g.mid_blocks;
+    g.slot_deferred = g.slot_frag + g.frag_blocks;
     g.slot_shade = g.slot_deferred + g.deferred_blocks;
     g.slot_total = g.slot_shade;
     return fv;
@@ -378,7 +384,7 @@ FrameView make_frame_view(rdr_renderer* r) {
 int fetch_counters(rdr_renderer* r, FrameCounters* out) {
     RDR_HIP(hipStreamSynchronize(r->stream));
     RDR_HIP(hipMemcpy(out, r->counters.ptr, sizeof(FrameCounters), hipMemcpyDeviceToHost));
-    RDR_CHECK(out->deferred_overflow == 0 && out->setup_overflow == 0 && out->bin_overflow == 0 && out->mid_overflow == 0,
+    RDR_CHECK(out->deferred_overflow == 0 && out->setup_overflow == 0 && out->bin_overflow == 0 && out->mid_overflow == 0 && out->frag_overflow == 0,
               "frame: a tile-path list (deferred triangles, setup records or bins) overflowed; triangles were dropped");
     RDR_CHECK(out->cmd_count <= r->commands.count && (uint64_t)out->vis_count + out->vis_mask_count <= r->visible.count,
               "frame: a work list overflowed");
@@ -533,6 +539,14 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
         if (r->deferred.alloc(n_def) || r->setup.alloc(n_def + n_def / 2) || r->setup_mask.alloc(n_def + n_def / 2) ||
             r->mid.alloc(n_def) || r->mid_mask.alloc(n_def)) return 1;
         if (r->bin_entries.alloc(std::max<size_t>(n_def * 4, (size_t)1 << 22))) return 1;
+        // small alpha-tested triangles and their covered pixels (at most 16 each): every LOD-0 triangle of the
+        // alpha-tested draws, capped like the lists above
+        const size_t n_frag = (size_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)r->masked_meshlets * 124, 1u << 12), 1u << 22);
+        if (r->frag_tri.alloc(n_frag) || r->frag_px.alloc(n_frag * 16)) return 1;
+        // zeroed once: a consumer that meets a never-written entry (only possible after an overflow, which is
+        // reported as an error) then reads a valid index
+        RDR_HIP(hipMemset(r->frag_tri.ptr, 0, n_frag * sizeof(FragTri)));
+        RDR_HIP(hipMemset(r->frag_px.ptr, 0, n_frag * 16 * sizeof(uint32_t)));
     }
     {
         // statistics slots for the largest launch geometry this scene can produce
@@ -736,6 +750,7 @@ int rdr_get_stats(rdr_renderer* r, rdr_stats* out) {
             st.fragments += p[3]; st.vertices_transformed += p[4];
         }
         for (uint32_t b = 0; b < g.mid_blocks; ++b) st.fragments += slots[g.slot_mid + b];
+        for (uint32_t b = 0; b < g.frag_blocks; ++b) st.fragments += slots[g.slot_frag + b];
         for (uint32_t b = 0; b < g.deferred_blocks; ++b) st.fragments += slots[g.slot_deferred + b];
         if (r->shaded) st.pixels_covered = fc.pixel_count;
         st.bin_entries = fc.bin_total;

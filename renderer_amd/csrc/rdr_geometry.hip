@@ -530,12 +530,22 @@ struct MeshletLds {
     uint32_t queue[128];                  // triangles that survived the cull tests: vertex bytes | index << 24
 };
 
+// What the alpha test needs per vertex besides the position: 1 / w and the uv set of the material's
+// albedo texture, computed once per vertex (the opaque instantiation carries none of it).
+template <bool MASK>
+struct MaskVertexLds {};
+template <>
+struct MaskVertexLds<true> {
+    float inv_w[64], u[64], v[64];
+};
+
 // MASK = false: meshlets of opaque draws (front of the visible list); MASK = true:
 // meshlets of alpha-tested draws (back of the list).  Two instantiations so that the
 // opaque one carries no uv / texture state in registers.
 template <bool MASK>
 __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
     __shared__ MeshletLds lds;
+    __shared__ MaskVertexLds<MASK> mlds;
     const uint32_t lane = threadIdx.x;
     const rdr_ubo& u = fv.ubo;
     const uint32_t n_opaque = min(fv.counters->vis_count, fv.visible_capacity);
@@ -589,6 +599,14 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
             if (!nc) project_xy(clip.x, clip.y, clip.w, half_w, half_h, X, Y);
             lds.X[lane] = X; lds.Y[lane] = Y;
             lds.clip[lane] = nc ? 1u : 0u;
+            if constexpr (MASK) {
+                if (at.has_tex) { // perspective-correct uv for the alpha test
+                    const rdr_vertex* vv = &sv.vertices[vi];
+                    mlds.inv_w[lane] = 1.0f / clip.w;
+                    mlds.u[lane] = at.uv_set ? vv->uv[2] : vv->uv[0];
+                    mlds.v[lane] = at.uv_set ? vv->uv[3] : vv->uv[1];
+                }
+            }
         }
         __syncthreads();
         if (has_next && lane < (vm_next.counts & 0xFFFFu)) // in flight during the triangle phase
@@ -634,6 +652,9 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
             bool defer = false; // clipped, large or pixel-heavy triangles go to the tile path
             bool mid = false;   // too many pixels for one lane: queued for k_mid_raster
             uint32_t ia = 0, ib = 0, ic = 0, ti = 0;
+            bool small_alpha = false; // MASK: a lane-sized triangle, its covered pixels go to k_alpha_frag
+            TriSetup<int32_t> alpha_ts;
+            alpha_ts.valid = false;
             // snapped vertices of the triangle with meshlet-local vertices (a, b, c), from the wave's LDS
             auto load_snap = [&](uint32_t a, uint32_t b, uint32_t c, SnapVert& s0, SnapVert& s1, SnapVert& s2) {
                 s0.X = lds.X[a]; s0.Y = lds.Y[a]; s0.z = lds.z[a];
@@ -643,15 +664,13 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
                 s0.u0 = s0.v0 = s0.u1 = s0.v1 = 0.0f;
                 s1.u0 = s1.v0 = s1.u1 = s1.v1 = 0.0f;
                 s2.u0 = s2.v0 = s2.u1 = s2.v1 = 0.0f;
-                if (MASK && at.has_tex) { // the alpha test needs perspective-correct uv
-                    const uint32_t* mv = sv.meshlet_vertices + m.vertex_offset;
-                    const rdr_vertex* va = &sv.vertices[mv[a] + mesh_vertex_offset];
-                    const rdr_vertex* vb = &sv.vertices[mv[b] + mesh_vertex_offset];
-                    const rdr_vertex* vc = &sv.vertices[mv[c] + mesh_vertex_offset];
-                    s0.inv_w = 1.0f / lds.cw[a]; s1.inv_w = 1.0f / lds.cw[b]; s2.inv_w = 1.0f / lds.cw[c];
-                    s0.u0 = va->uv[0]; s0.v0 = va->uv[1]; s0.u1 = va->uv[2]; s0.v1 = va->uv[3];
-                    s1.u0 = vb->uv[0]; s1.v0 = vb->uv[1]; s1.u1 = vb->uv[2]; s1.v1 = vb->uv[3];
-                    s2.u0 = vc->uv[0]; s2.v0 = vc->uv[1]; s2.u1 = vc->uv[2]; s2.v1 = vc->uv[3];
+                if constexpr (MASK) {
+                    if (at.has_tex) { // both uv slots carry the set the albedo texture uses: whichever the test picks is right
+                        s0.inv_w = mlds.inv_w[a]; s1.inv_w = mlds.inv_w[b]; s2.inv_w = mlds.inv_w[c];
+                        s0.u0 = s0.u1 = mlds.u[a]; s0.v0 = s0.v1 = mlds.v[a];
+                        s1.u0 = s1.u1 = mlds.u[b]; s1.v0 = s1.v1 = mlds.v[b];
+                        s2.u0 = s2.u1 = mlds.u[c]; s2.v0 = s2.v1 = mlds.v[c];
+                    }
                 }
             };
             if (q0 + lane < n_queued) {
@@ -671,8 +690,78 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
                         if (ts.valid) {
                             const int npx = (ts.px1 - ts.px0 + 1) * (ts.py1 - ts.py0 + 1);
                             defer = npx > (int)fv.mid_max_pixels;
-                            mid = !defer && npx > (int)fv.lane_max_pixels;
-                            if (!defer && !mid) st_frags += scan_lane<int32_t, MASK>(sv, fv, ts, at, (vm.instance << 7) | ti);
+                            mid = !defer && npx > (int)(MASK ? min(fv.lane_max_pixels, kLaneMaxPixels) : fv.lane_max_pixels);
+                            if (!defer && !mid) {
+                                if constexpr (MASK) {
+                                    small_alpha = true;
+                                    alpha_ts = ts;
+                                } else {
+                                    st_frags += scan_lane<int32_t, MASK>(sv, fv, ts, at, (vm.instance << 7) | ti);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            // Alpha-tested small triangles: a covered pixel costs three perspective uv evaluations and a
+            // trilinear sample, and a lane's triangle covers anything from 0 to 16 pixels, so scanning here
+            // would leave most of the wave waiting for its biggest triangles (and the sampler's registers
+            // would halve this kernel's occupancy).  The lanes only find their covered pixels (cheap) and
+            // queue (triangle, pixel) pairs; k_alpha_frag works through them with one fragment per lane.
+            if constexpr (MASK) {
+                uint32_t cmask = 0; // bit k: pixel k of the box (row-major) has its centre inside
+                if (small_alpha) {
+                    const TriSetup<int32_t>& qt = alpha_ts;
+                    int32_t r01, r12, r20;
+                    edges_at<int32_t>(qt, qt.px0, qt.py0, r01, r12, r20);
+                    uint32_t k = 0;
+                    for (int py = qt.py0; py <= qt.py1; ++py) {
+                        int32_t e01 = r01, e12 = r12, e20 = r20;
+                        for (int px = qt.px0; px <= qt.px1; ++px, ++k) {
+                            cmask |= (((e01 + qt.bias01) | (e12 + qt.bias12) | (e20 + qt.bias20)) >= 0) ? (1u << k) : 0u;
+                            e01 -= qt.dy01 * 256; e12 -= qt.dy12 * 256; e20 -= qt.dy20 * 256;
+                        }
+                        r01 += qt.dx01 * 256; r12 += qt.dx12 * 256; r20 += qt.dx20 * 256;
+                    }
+                }
+                const uint32_t n_cov = (uint32_t)__popc(cmask);
+                const unsigned long long tm = __ballot(n_cov != 0u);
+                if (tm) {
+                    const uint32_t seg = blockIdx.x % kFragSegments;
+                    const uint32_t cap_t = fv.frag_tri_capacity / kFragSegments, cap_p = fv.frag_px_capacity / kFragSegments;
+                    const uint32_t incl = wave_scan_inclusive(n_cov, lane);
+                    const uint32_t total = __shfl(incl, 63, 64);
+                    const int leader = __ffsll((long long)tm) - 1;
+                    uint32_t base_t = 0, base_p = 0;
+                    if ((int)lane == leader) {
+                        base_t = atomicAdd(&fv.counters->frag_tri_seg[seg * 32u], (uint32_t)__popcll(tm));
+                        base_p = atomicAdd(&fv.counters->frag_px_seg[seg * 32u], total);
+                    }
+                    base_t = __shfl(base_t, leader, 64);
+                    base_p = __shfl(base_p, leader, 64);
+                    if (n_cov) {
+                        const uint32_t slot_t = base_t + ballot_rank(tm), first_p = base_p + incl - n_cov;
+                        if (slot_t < cap_t && first_p + n_cov <= cap_p) {
+                            const TriSetup<int32_t>& qt = alpha_ts;
+                            const uint32_t gt = seg * cap_t + slot_t;
+                            FragTri r;
+                            r.X[0] = qt.v0.X; r.X[1] = qt.v1.X; r.X[2] = qt.v2.X;
+                            r.Y[0] = qt.v0.Y; r.Y[1] = qt.v1.Y; r.Y[2] = qt.v2.Y;
+                            r.z0 = qt.v0.z; r.dz1 = qt.dz1; r.dz2 = qt.dz2; r.inv_area = qt.inv_area;
+                            r.inv_w[0] = qt.v0.inv_w; r.inv_w[1] = qt.v1.inv_w; r.inv_w[2] = qt.v2.inv_w;
+                            const bool set1 = at.uv_set != 0u;
+                            r.u[0] = set1 ? qt.v0.u1 : qt.v0.u0; r.u[1] = set1 ? qt.v1.u1 : qt.v1.u0; r.u[2] = set1 ? qt.v2.u1 : qt.v2.u0;
+                            r.v[0] = set1 ? qt.v0.v1 : qt.v0.v0; r.v[1] = set1 ? qt.v1.v1 : qt.v1.v0; r.v[2] = set1 ? qt.v2.v1 : qt.v2.v0;
+                            r.origin = (uint32_t)qt.px0 | ((uint32_t)qt.py0 << 16);
+                            r.bw = (uint32_t)(qt.px1 - qt.px0 + 1);
+                            r.id = (vm.instance << 7) | ti;
+                            r.draw_id = vm.draw_id;
+                            r._pad = 0;
+                            fv.frag_tri[gt] = r;
+                            uint32_t* dst = fv.frag_px + (size_t)seg * cap_p + first_p;
+                            for (uint32_t m2 = cmask; m2; m2 &= m2 - 1u) *dst++ = (gt << 4) | (uint32_t)(__ffs((int)m2) - 1);
+                        } else {
+                            atomicAdd(&fv.counters->frag_overflow, 1u);
                         }
                     }
                 }
@@ -802,6 +891,61 @@ __global__ __launch_bounds__(256) void k_mid_raster(SceneView sv, FrameView fv) 
         if (lane == 0) wg_frags[threadIdx.x >> 6] = f;
         __syncthreads();
         if (threadIdx.x == 0) stat_store(fv, fv.grid.slot_mid + blockIdx.x, wg_frags[0] + wg_frags[1] + wg_frags[2] + wg_frags[3]);
+    }
+}
+
+// The covered pixels of small alpha-tested triangles queued by k_raster<true>: one fragment per
+// lane (alpha test, depth, atomic), whatever triangle it belongs to.
+__global__ __launch_bounds__(256) void k_alpha_frag(SceneView sv, FrameView fv) {
+    __shared__ uint32_t seg_end[kFragSegments], seg_cnt[kFragSegments];
+    __shared__ uint32_t wg_frags[4];
+    const uint32_t lane = lane_id();
+    const uint32_t cap_p = fv.frag_px_capacity / kFragSegments;
+    if (threadIdx.x < 64) {
+        const uint32_t n = lane < kFragSegments ? min(fv.counters->frag_px_seg[lane * 32u], cap_p) : 0u;
+        const uint32_t incl = wave_scan_inclusive(n, lane);
+        if (lane < kFragSegments) { seg_end[lane] = incl; seg_cnt[lane] = n; }
+    }
+    __syncthreads();
+    const uint32_t count = seg_end[kFragSegments - 1];
+    uint32_t frags = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        uint32_t seg = 0; // first segment whose running total exceeds i
+#pragma unroll
+        for (uint32_t step = kFragSegments / 2; step; step >>= 1)
+            if (seg_end[seg + step - 1] <= i) seg += step;
+        const uint32_t e = fv.frag_px[(size_t)seg * cap_p + (i - (seg_end[seg] - seg_cnt[seg]))];
+        if ((e >> 4) >= fv.frag_tri_capacity) continue; // cannot happen unless a queue overflowed and left a hole
+        const FragTri r = fv.frag_tri[e >> 4];
+        const uint32_t k = e & 15u, dy = k / max(r.bw, 1u), dx = k - dy * r.bw;
+        const int px = (int)(r.origin & 0xFFFFu) + (int)dx, py = (int)(r.origin >> 16) + (int)dy;
+        if (px >= (int)fv.width || py >= (int)fv.height || r.draw_id >= sv.draw_count) continue; // same
+        const AlphaTest at = make_alpha_test(sv, sv.draws[r.draw_id]);
+        TriSetup<int32_t> ft;
+        ft.v0 = SnapVert{}; ft.v1 = SnapVert{}; ft.v2 = SnapVert{};
+        ft.v0.X = r.X[0]; ft.v1.X = r.X[1]; ft.v2.X = r.X[2];
+        ft.v0.Y = r.Y[0]; ft.v1.Y = r.Y[1]; ft.v2.Y = r.Y[2];
+        ft.v0.z = r.z0; ft.dz1 = r.dz1; ft.dz2 = r.dz2; ft.inv_area = r.inv_area;
+        ft.v0.inv_w = r.inv_w[0]; ft.v1.inv_w = r.inv_w[1]; ft.v2.inv_w = r.inv_w[2];
+        ft.v0.u0 = ft.v0.u1 = r.u[0]; ft.v1.u0 = ft.v1.u1 = r.u[1]; ft.v2.u0 = ft.v2.u1 = r.u[2];
+        ft.v0.v0 = ft.v0.v1 = r.v[0]; ft.v1.v0 = ft.v1.v1 = r.v[1]; ft.v2.v0 = ft.v2.v1 = r.v[2];
+        ft.dx01 = ft.v1.X - ft.v0.X; ft.dy01 = ft.v1.Y - ft.v0.Y;
+        ft.dx12 = ft.v2.X - ft.v1.X; ft.dy12 = ft.v2.Y - ft.v1.Y;
+        ft.dx20 = ft.v0.X - ft.v2.X; ft.dy20 = ft.v0.Y - ft.v2.Y;
+        ft.bias01 = (ft.dy01 < 0 || (ft.dy01 == 0 && ft.dx01 > 0)) ? 0 : -1;
+        ft.bias12 = (ft.dy12 < 0 || (ft.dy12 == 0 && ft.dx12 > 0)) ? 0 : -1;
+        ft.bias20 = (ft.dy20 < 0 || (ft.dy20 == 0 && ft.dx20 > 0)) ? 0 : -1;
+        ft.px0 = ft.px1 = px; ft.py0 = ft.py1 = py;
+        ft.valid = true;
+        int32_t e01, e12, e20;
+        edges_at<int32_t>(ft, px, py, e01, e12, e20);
+        frags += shade_sample<int32_t, true>(sv, fv, ft, at, px, py, e01, e12, e20, r.id);
+    }
+    if (fv.collect_stats) {
+        const uint32_t f = wave_sum(frags);
+        if (lane == 0) wg_frags[threadIdx.x >> 6] = f;
+        __syncthreads();
+        if (threadIdx.x == 0) stat_store(fv, fv.grid.slot_frag + blockIdx.x, wg_frags[0] + wg_frags[1] + wg_frags[2] + wg_frags[3]);
     }
 }
 
@@ -1293,6 +1437,7 @@ __global__ __launch_bounds__(256) void k_phase_reset(FrameView fv) {
         c->setup_count = 0; c->bin_total = 0;
     }
     if (gi < kMidSegments) fv.counters->mid_seg[gi * 32u] = 0u;
+    if (gi < kFragSegments) { fv.counters->frag_tri_seg[gi * 32u] = 0u; fv.counters->frag_px_seg[gi * 32u] = 0u; }
 }
 
 __global__ __launch_bounds__(256) void k_clear(unsigned long long* vis, size_t n, FrameCounters* counters, uint32_t* tile_count,
@@ -1343,6 +1488,8 @@ int rdr_geometry_residency(GeometryResidency* out) {
     out->raster_mask = (uint32_t)(n * cus);
     RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mid_raster, 256, 0));
     out->mid_raster = (uint32_t)(n * cus);
+    RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_alpha_frag, 256, 0));
+    out->alpha_frag = (uint32_t)(n * cus);
     return 0;
 }
 
@@ -1357,6 +1504,7 @@ int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t st
         // persistent grids: the work-list lengths live in device memory
         hipLaunchKernelGGL(k_raster<false>, dim3(f.grid.raster_blocks), dim3(64), 0, stream, sv, f);
         hipLaunchKernelGGL(k_raster<true>, dim3(f.grid.raster_mask_blocks), dim3(64), 0, stream, sv, f);
+        hipLaunchKernelGGL(k_alpha_frag, dim3(f.grid.frag_blocks), dim3(256), 0, stream, sv, f);
         hipLaunchKernelGGL(k_mid_raster, dim3(f.grid.mid_blocks), dim3(256), 0, stream, sv, f);
         if (mid_event) (void)hipEventRecord(*mid_event, stream);
         hipLaunchKernelGGL(k_tile_setup, dim3(256), dim3(256), 0, stream, sv, f);

@@ -88,6 +88,19 @@ struct SetupMask {
 };
 static_assert(sizeof(SetupMask) == 64, "SetupMask layout");
 
+// A small alpha-tested triangle queued for k_alpha_frag (already oriented for scanning), 96 B.
+struct FragTri {
+    int32_t X[3], Y[3];
+    float z0, dz1, dz2, inv_area;
+    float inv_w[3], u[3], v[3]; // uv of the set the material's albedo texture uses
+    uint32_t origin;            // px0 | py0 << 16 of the pixel box
+    uint32_t bw;                // width of the pixel box (box area <= 16)
+    uint32_t id;
+    uint32_t draw_id;
+    uint32_t _pad;
+};
+static_assert(sizeof(FragTri) == 96, "FragTri layout");
+
 // Heads of the per-frame work lists.
 struct FrameCounters {
     uint32_t cmd_count;
@@ -110,9 +123,16 @@ struct FrameCounters {
     // (about 10 ns each): the queue is cut into segments with counters 128 bytes apart (word
     // s * 32 counts segment s) and a workgroup always uses segment blockIdx % kMidSegments.
     uint32_t mid_seg[32 * 32];
+    // Small alpha-tested triangles and their covered pixels, queued by k_raster<true> for k_alpha_frag:
+    // segmented like the mid queue (word s * 32 counts segment s).
+    uint32_t frag_tri_seg[32 * 32];
+    uint32_t frag_px_seg[32 * 32];
+    uint32_t frag_overflow;
+    uint32_t _pad_frag[31];
 };
 constexpr uint32_t kMidSegments = 32;
-static_assert(sizeof(FrameCounters) == 192 + 4096, "FrameCounters layout");
+constexpr uint32_t kFragSegments = 32;
+static_assert(sizeof(FrameCounters) == 192 + 4096 + 8192 + 128, "FrameCounters layout");
 
 struct GpuImage {
     uint32_t width, height, mip_count, format;
@@ -261,8 +281,8 @@ struct SceneView {
 
 // Launch geometry of one frame and where each kernel's workgroups put their statistics.
 struct GridPlan {
-    uint32_t draw_blocks, cull_blocks, raster_blocks, raster_mask_blocks, mid_blocks, deferred_blocks, shade_blocks_x, shade_blocks_y;
-    uint32_t slot_draw, slot_cull, slot_raster, slot_mid, slot_deferred, slot_shade, slot_total;
+    uint32_t draw_blocks, cull_blocks, raster_blocks, raster_mask_blocks, mid_blocks, frag_blocks, deferred_blocks, shade_blocks_x, shade_blocks_y;
+    uint32_t slot_draw, slot_cull, slot_raster, slot_mid, slot_frag, slot_deferred, slot_shade, slot_total;
 };
 constexpr uint32_t kCullSlots = 4, kRasterSlots = 8;
 
@@ -291,6 +311,9 @@ struct FrameView {
     SetupTri* mid;        // scan set-ups of mid-sized triangles (k_raster -> k_mid_raster)
     SetupMask* mid_mask;
     uint32_t mid_capacity;
+    FragTri* frag_tri;          // small alpha-tested triangles (k_raster<true> -> k_alpha_frag), kFragSegments segments
+    uint32_t* frag_px;          // their covered pixels: triangle slot << 4 | index of the pixel in its box
+    uint32_t frag_tri_capacity, frag_px_capacity;
     // Routing of a triangle whose bounding box is at most 64 px on a side, by the pixels in
     // the box: up to lane_max_pixels one lane of k_raster scans it, up to mid_max_pixels it is
     // queued for k_mid_raster (a wave per triangle, 8x8 pixels per step), beyond that (and
@@ -332,7 +355,7 @@ void rdr_build_tlas(const rdr_scene_desc& s, const float* transforms, HostBvh& i
 // ---- kernel launchers (rdr_geometry.hip / rdr_shade.hip) ---------------------
 int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev);
 struct GeometryResidency {
-    uint32_t meshlet_cull, raster, raster_mask, mid_raster; // resident workgroups on the whole device
+    uint32_t meshlet_cull, raster, raster_mask, mid_raster, alpha_frag; // resident workgroups on the whole device
 };
 int rdr_geometry_residency(GeometryResidency* out);
 int rdr_launch_shadow(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev); // classify + shadow rays
