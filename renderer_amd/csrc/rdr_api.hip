@@ -90,6 +90,7 @@ struct rdr_renderer {
     // scene resources
     DeviceBuffer<rdr_vertex> vertices;
     DeviceBuffer<float> pos_x, pos_y, pos_z;
+    DeviceBuffer<float4> uv_sets;
     DeviceBuffer<uint32_t> meshlet_vertices;
     DeviceBuffer<uint8_t> meshlet_triangles;
     DeviceBuffer<rdr_meshlet> meshlets;
@@ -493,6 +494,12 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
         }
         if (r->pos_x.upload(px.data(), px.size()) || r->pos_y.upload(py.data(), py.size()) || r->pos_z.upload(pz.data(), pz.size())) return 1;
     }
+    { // both uv sets as one 16-byte element: the alpha-tested rasteriser reads uv per vertex and nothing else of it
+        std::vector<float4> uv(s.vertex_count);
+        for (uint32_t i = 0; i < s.vertex_count; ++i)
+            uv[i] = make_float4(s.vertices[i].uv[0], s.vertices[i].uv[1], s.vertices[i].uv[2], s.vertices[i].uv[3]);
+        if (r->uv_sets.upload(uv.data(), uv.size())) return 1;
+    }
     if (r->meshlet_vertices.upload(s.meshlet_vertices, s.meshlet_vertex_count)) return 1;
     {
         // a few bytes of slack: triangle indices are fetched with byte loads only, but keep the tail mapped
@@ -593,6 +600,7 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
     SceneView& sv = r->sv;
     sv.vertices = r->vertices.ptr;
     sv.pos_x = r->pos_x.ptr; sv.pos_y = r->pos_y.ptr; sv.pos_z = r->pos_z.ptr;
+    sv.uv_sets = r->uv_sets.ptr;
     sv.meshlet_vertices = r->meshlet_vertices.ptr;
     sv.meshlet_triangles = r->meshlet_triangles.ptr;
     sv.meshlets = r->meshlets.ptr;

@@ -543,7 +543,7 @@ struct MaskVertexLds<true> {
 // meshlets of alpha-tested draws (back of the list).  Two instantiations so that the
 // opaque one carries no uv / texture state in registers.
 template <bool MASK>
-__global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : 1))) void k_raster(SceneView sv, FrameView fv) {
     __shared__ MeshletLds lds;
     __shared__ MaskVertexLds<MASK> mlds;
     const uint32_t lane = threadIdx.x;
@@ -601,10 +601,10 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
             lds.clip[lane] = nc ? 1u : 0u;
             if constexpr (MASK) {
                 if (at.has_tex) { // perspective-correct uv for the alpha test
-                    const rdr_vertex* vv = &sv.vertices[vi];
+                    const float4 uv = sv.uv_sets[vi];
                     mlds.inv_w[lane] = 1.0f / clip.w;
-                    mlds.u[lane] = at.uv_set ? vv->uv[2] : vv->uv[0];
-                    mlds.v[lane] = at.uv_set ? vv->uv[3] : vv->uv[1];
+                    mlds.u[lane] = at.uv_set ? uv.z : uv.x;
+                    mlds.v[lane] = at.uv_set ? uv.w : uv.y;
                 }
             }
         }
@@ -652,9 +652,8 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
             bool defer = false; // clipped, large or pixel-heavy triangles go to the tile path
             bool mid = false;   // too many pixels for one lane: queued for k_mid_raster
             uint32_t ia = 0, ib = 0, ic = 0, ti = 0;
-            bool small_alpha = false; // MASK: a lane-sized triangle, its covered pixels go to k_alpha_frag
-            TriSetup<int32_t> alpha_ts;
-            alpha_ts.valid = false;
+            uint32_t cmask = 0; // MASK: a lane-sized triangle's covered pixels (bit k: pixel k of its box, row-major)
+            FragTri frag_rec;   // ... and what k_alpha_frag needs of the triangle
             // snapped vertices of the triangle with meshlet-local vertices (a, b, c), from the wave's LDS
             auto load_snap = [&](uint32_t a, uint32_t b, uint32_t c, SnapVert& s0, SnapVert& s1, SnapVert& s2) {
                 s0.X = lds.X[a]; s0.Y = lds.Y[a]; s0.z = lds.z[a];
@@ -693,8 +692,29 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
                             mid = !defer && npx > (int)(MASK ? min(fv.lane_max_pixels, kLaneMaxPixels) : fv.lane_max_pixels);
                             if (!defer && !mid) {
                                 if constexpr (MASK) {
-                                    small_alpha = true;
-                                    alpha_ts = ts;
+                                    int32_t r01, r12, r20;
+                                    edges_at<int32_t>(ts, ts.px0, ts.py0, r01, r12, r20);
+                                    uint32_t k = 0;
+                                    for (int py = ts.py0; py <= ts.py1; ++py) {
+                                        int32_t e01 = r01, e12 = r12, e20 = r20;
+                                        for (int px = ts.px0; px <= ts.px1; ++px, ++k) {
+                                            cmask |= (((e01 + ts.bias01) | (e12 + ts.bias12) | (e20 + ts.bias20)) >= 0) ? (1u << k) : 0u;
+                                            e01 -= ts.dy01 * 256; e12 -= ts.dy12 * 256; e20 -= ts.dy20 * 256;
+                                        }
+                                        r01 += ts.dx01 * 256; r12 += ts.dx12 * 256; r20 += ts.dx20 * 256;
+                                    }
+                                    FragTri& r = frag_rec;
+                                    r.X[0] = ts.v0.X; r.X[1] = ts.v1.X; r.X[2] = ts.v2.X;
+                                    r.Y[0] = ts.v0.Y; r.Y[1] = ts.v1.Y; r.Y[2] = ts.v2.Y;
+                                    r.z0 = ts.v0.z; r.dz1 = ts.dz1; r.dz2 = ts.dz2; r.inv_area = ts.inv_area;
+                                    r.inv_w[0] = ts.v0.inv_w; r.inv_w[1] = ts.v1.inv_w; r.inv_w[2] = ts.v2.inv_w;
+                                    r.u[0] = ts.v0.u0; r.u[1] = ts.v1.u0; r.u[2] = ts.v2.u0; // both uv slots hold the albedo set
+                                    r.v[0] = ts.v0.v0; r.v[1] = ts.v1.v0; r.v[2] = ts.v2.v0;
+                                    r.origin = (uint32_t)ts.px0 | ((uint32_t)ts.py0 << 16);
+                                    r.bw = (uint32_t)(ts.px1 - ts.px0 + 1);
+                                    r.id = (vm.instance << 7) | ti;
+                                    r.draw_id = vm.draw_id;
+                                    r._pad = 0;
                                 } else {
                                     st_frags += scan_lane<int32_t, MASK>(sv, fv, ts, at, (vm.instance << 7) | ti);
                                 }
@@ -709,21 +729,6 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
             // would halve this kernel's occupancy).  The lanes only find their covered pixels (cheap) and
             // queue (triangle, pixel) pairs; k_alpha_frag works through them with one fragment per lane.
             if constexpr (MASK) {
-                uint32_t cmask = 0; // bit k: pixel k of the box (row-major) has its centre inside
-                if (small_alpha) {
-                    const TriSetup<int32_t>& qt = alpha_ts;
-                    int32_t r01, r12, r20;
-                    edges_at<int32_t>(qt, qt.px0, qt.py0, r01, r12, r20);
-                    uint32_t k = 0;
-                    for (int py = qt.py0; py <= qt.py1; ++py) {
-                        int32_t e01 = r01, e12 = r12, e20 = r20;
-                        for (int px = qt.px0; px <= qt.px1; ++px, ++k) {
-                            cmask |= (((e01 + qt.bias01) | (e12 + qt.bias12) | (e20 + qt.bias20)) >= 0) ? (1u << k) : 0u;
-                            e01 -= qt.dy01 * 256; e12 -= qt.dy12 * 256; e20 -= qt.dy20 * 256;
-                        }
-                        r01 += qt.dx01 * 256; r12 += qt.dx12 * 256; r20 += qt.dx20 * 256;
-                    }
-                }
                 const uint32_t n_cov = (uint32_t)__popc(cmask);
                 const unsigned long long tm = __ballot(n_cov != 0u);
                 if (tm) {
@@ -742,22 +747,8 @@ __global__ __launch_bounds__(64) void k_raster(SceneView sv, FrameView fv) {
                     if (n_cov) {
                         const uint32_t slot_t = base_t + ballot_rank(tm), first_p = base_p + incl - n_cov;
                         if (slot_t < cap_t && first_p + n_cov <= cap_p) {
-                            const TriSetup<int32_t>& qt = alpha_ts;
                             const uint32_t gt = seg * cap_t + slot_t;
-                            FragTri r;
-                            r.X[0] = qt.v0.X; r.X[1] = qt.v1.X; r.X[2] = qt.v2.X;
-                            r.Y[0] = qt.v0.Y; r.Y[1] = qt.v1.Y; r.Y[2] = qt.v2.Y;
-                            r.z0 = qt.v0.z; r.dz1 = qt.dz1; r.dz2 = qt.dz2; r.inv_area = qt.inv_area;
-                            r.inv_w[0] = qt.v0.inv_w; r.inv_w[1] = qt.v1.inv_w; r.inv_w[2] = qt.v2.inv_w;
-                            const bool set1 = at.uv_set != 0u;
-                            r.u[0] = set1 ? qt.v0.u1 : qt.v0.u0; r.u[1] = set1 ? qt.v1.u1 : qt.v1.u0; r.u[2] = set1 ? qt.v2.u1 : qt.v2.u0;
-                            r.v[0] = set1 ? qt.v0.v1 : qt.v0.v0; r.v[1] = set1 ? qt.v1.v1 : qt.v1.v0; r.v[2] = set1 ? qt.v2.v1 : qt.v2.v0;
-                            r.origin = (uint32_t)qt.px0 | ((uint32_t)qt.py0 << 16);
-                            r.bw = (uint32_t)(qt.px1 - qt.px0 + 1);
-                            r.id = (vm.instance << 7) | ti;
-                            r.draw_id = vm.draw_id;
-                            r._pad = 0;
-                            fv.frag_tri[gt] = r;
+                            fv.frag_tri[gt] = frag_rec;
                             uint32_t* dst = fv.frag_px + (size_t)seg * cap_p + first_p;
                             for (uint32_t m2 = cmask; m2; m2 &= m2 - 1u) *dst++ = (gt << 4) | (uint32_t)(__ffs((int)m2) - 1);
                         } else {

@@ -255,6 +255,7 @@ struct SceneView {
     const float* pos_x;
     const float* pos_y;
     const float* pos_z;
+    const float4* uv_sets;      // uv0.xy | uv1.zw per vertex, apart from the 64-byte vertex (the rasteriser's alpha test)
     const uint32_t* meshlet_vertices;
     const uint8_t* meshlet_triangles;
     const rdr_meshlet* meshlets;
