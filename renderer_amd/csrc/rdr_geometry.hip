@@ -537,6 +537,7 @@ struct MaskVertexLds {};
 template <>
 struct MaskVertexLds<true> {
     float inv_w[64], u[64], v[64];
+    FragTri rec[64]; // a lane's record for k_alpha_frag, staged here so that it does not sit in registers
 };
 
 // MASK = false: meshlets of opaque draws (front of the visible list); MASK = true:
@@ -653,7 +654,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : 1
             bool mid = false;   // too many pixels for one lane: queued for k_mid_raster
             uint32_t ia = 0, ib = 0, ic = 0, ti = 0;
             uint32_t cmask = 0; // MASK: a lane-sized triangle's covered pixels (bit k: pixel k of its box, row-major)
-            FragTri frag_rec;   // ... and what k_alpha_frag needs of the triangle
+                                // (what k_alpha_frag needs of the triangle is staged in mlds.rec[lane])
             // snapped vertices of the triangle with meshlet-local vertices (a, b, c), from the wave's LDS
             auto load_snap = [&](uint32_t a, uint32_t b, uint32_t c, SnapVert& s0, SnapVert& s1, SnapVert& s2) {
                 s0.X = lds.X[a]; s0.Y = lds.Y[a]; s0.z = lds.z[a];
@@ -703,7 +704,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : 1
                                         }
                                         r01 += ts.dx01 * 256; r12 += ts.dx12 * 256; r20 += ts.dx20 * 256;
                                     }
-                                    FragTri& r = frag_rec;
+                                    FragTri& r = mlds.rec[lane];
                                     r.X[0] = ts.v0.X; r.X[1] = ts.v1.X; r.X[2] = ts.v2.X;
                                     r.Y[0] = ts.v0.Y; r.Y[1] = ts.v1.Y; r.Y[2] = ts.v2.Y;
                                     r.z0 = ts.v0.z; r.dz1 = ts.dz1; r.dz2 = ts.dz2; r.inv_area = ts.inv_area;
@@ -737,18 +738,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : 1
                     const uint32_t incl = wave_scan_inclusive(n_cov, lane);
                     const uint32_t total = __shfl(incl, 63, 64);
                     const int leader = __ffsll((long long)tm) - 1;
-                    uint32_t base_t = 0, base_p = 0;
-                    if ((int)lane == leader) {
-                        base_t = atomicAdd(&fv.counters->frag_tri_seg[seg * 32u], (uint32_t)__popcll(tm));
-                        base_p = atomicAdd(&fv.counters->frag_px_seg[seg * 32u], total);
-                    }
-                    base_t = __shfl(base_t, leader, 64);
-                    base_p = __shfl(base_p, leader, 64);
+                    unsigned long long base = 0;
+                    if ((int)lane == leader)
+                        base = atomicAdd(&fv.counters->frag_seg[seg * 16u], ((unsigned long long)__popcll(tm) << 32) | total);
+                    base = __shfl(base, leader, 64);
+                    const uint32_t base_t = (uint32_t)(base >> 32), base_p = (uint32_t)base;
                     if (n_cov) {
                         const uint32_t slot_t = base_t + ballot_rank(tm), first_p = base_p + incl - n_cov;
                         if (slot_t < cap_t && first_p + n_cov <= cap_p) {
                             const uint32_t gt = seg * cap_t + slot_t;
-                            fv.frag_tri[gt] = frag_rec;
+                            const uint4* src = reinterpret_cast<const uint4*>(&mlds.rec[lane]);
+                            uint4* out = reinterpret_cast<uint4*>(&fv.frag_tri[gt]);
+#pragma unroll
+                            for (int c = 0; c < (int)(sizeof(FragTri) / 16); ++c) out[c] = src[c];
                             uint32_t* dst = fv.frag_px + (size_t)seg * cap_p + first_p;
                             for (uint32_t m2 = cmask; m2; m2 &= m2 - 1u) *dst++ = (gt << 4) | (uint32_t)(__ffs((int)m2) - 1);
                         } else {
@@ -893,7 +895,7 @@ __global__ __launch_bounds__(256) void k_alpha_frag(SceneView sv, FrameView fv) 
     const uint32_t lane = lane_id();
     const uint32_t cap_p = fv.frag_px_capacity / kFragSegments;
     if (threadIdx.x < 64) {
-        const uint32_t n = lane < kFragSegments ? min(fv.counters->frag_px_seg[lane * 32u], cap_p) : 0u;
+        const uint32_t n = lane < kFragSegments ? min((uint32_t)fv.counters->frag_seg[lane * 16u], cap_p) : 0u;
         const uint32_t incl = wave_scan_inclusive(n, lane);
         if (lane < kFragSegments) { seg_end[lane] = incl; seg_cnt[lane] = n; }
     }
@@ -1428,7 +1430,7 @@ __global__ __launch_bounds__(256) void k_phase_reset(FrameView fv) {
         c->setup_count = 0; c->bin_total = 0;
     }
     if (gi < kMidSegments) fv.counters->mid_seg[gi * 32u] = 0u;
-    if (gi < kFragSegments) { fv.counters->frag_tri_seg[gi * 32u] = 0u; fv.counters->frag_px_seg[gi * 32u] = 0u; }
+    if (gi < kFragSegments) fv.counters->frag_seg[gi * 16u] = 0ull;
 }
 
 __global__ __launch_bounds__(256) void k_clear(unsigned long long* vis, size_t n, FrameCounters* counters, uint32_t* tile_count,

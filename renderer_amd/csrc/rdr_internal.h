@@ -124,9 +124,9 @@ struct FrameCounters {
     // s * 32 counts segment s) and a workgroup always uses segment blockIdx % kMidSegments.
     uint32_t mid_seg[32 * 32];
     // Small alpha-tested triangles and their covered pixels, queued by k_raster<true> for k_alpha_frag:
-    // segmented like the mid queue (word s * 32 counts segment s).
-    uint32_t frag_tri_seg[32 * 32];
-    uint32_t frag_px_seg[32 * 32];
+    // segmented like the mid queue; one 64-bit counter per segment (128 bytes apart) so that a wave
+    // reserves its triangle slots and its pixel slots with a single atomic.
+    unsigned long long frag_seg[32 * 32]; // word s * 16: covered pixels (low half) and triangles (high half) of segment s
     uint32_t frag_overflow;
     uint32_t _pad_frag[31];
 };
