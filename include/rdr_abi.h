@@ -151,6 +151,14 @@ typedef struct rdr_ubo {
 #define RDR_FORMAT_RGBA8_UNORM 0u
 #define RDR_FORMAT_RGBA8_SRGB 1u
 #define RDR_FORMAT_RGBA32F 2u
+/* Block-compressed 2D images, as a .dds file stores them (image_loader.rs:63-135 hands the blocks
+ * to Vulkan; the sRGB variants of BC1-BC3 are bound as UNORM there, :72-74, so there is one
+ * code per block layout).  Decoded to RGBA8_UNORM on the GPU when the scene is uploaded.
+ * Level i holds ceil(w_i / 4) x ceil(h_i / 4) blocks of 8 (BC1, BC4) or 16 bytes, row-major. */
+#define RDR_FORMAT_BC1 3u /* RGB565 end points, 1-bit punch-through alpha */
+#define RDR_FORMAT_BC2 4u /* explicit 4-bit alpha + BC1 colours */
+#define RDR_FORMAT_BC3 5u /* interpolated alpha + BC1 colours */
+#define RDR_FORMAT_BC4 6u /* one interpolated channel (red), unorm */
 
 /* 2D image: mip levels tightly packed, level 0 first, rows top to bottom;
  * level i is max(1,width>>i) x max(1,height>>i). */
@@ -160,6 +168,12 @@ typedef struct rdr_image_desc {
     uint32_t mip_count;
     uint32_t format;
 } rdr_image_desc;
+
+/* Decode a block-compressed mip chain (RDR_FORMAT_BC1..BC4) to tightly packed RGBA8 levels, host
+ * memory to host memory, with the kernel rdr_set_scene uses at upload.  What the sampler hardware
+ * does per fetch behind vkCmdCopyBufferToImage of a BC image (image_loader.rs:96-121). */
+int rdr_decode_bc(int device, uint32_t format, uint32_t width, uint32_t height, uint32_t mip_count, const void* blocks,
+                  size_t block_bytes, void* out_rgba8);
 
 /* Cubemap: mip-major; within a mip the six faces in Vulkan layer order
  * +X,-X,+Y,-Y,+Z,-Z; level i is max(1,size>>i) square. */

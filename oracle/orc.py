@@ -38,6 +38,7 @@ def lib():
         L.orc_skybox.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.Ubo), C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_bake_brdf_lut.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_bake_env_map.argtypes = [C.POINTER(abi.CubemapDesc), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_decode_bc.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_num_threads.restype = C.c_int
         _LIB = L
     return _LIB

@@ -247,17 +247,24 @@ int validate_scene(const rdr_scene_desc& s) {
         const rdr_image_desc& im = s.images[i];
         if (!im.data) continue;
         RDR_CHECK(im.width && im.height && im.mip_count >= 1 && im.mip_count <= 17, "scene: image dimensions / mip count invalid");
-        RDR_CHECK(im.format <= RDR_FORMAT_RGBA32F, "scene: unknown image format");
+        RDR_CHECK(im.format <= RDR_FORMAT_BC4, "scene: unknown image format");
     }
     return 0;
 }
 
 struct TexelPacker {
     std::vector<uint8_t> blob;
-    size_t append(const void* src, size_t bytes) {
+    // block-compressed images: room for the decoded texels is reserved in the blob and the blocks are
+    // expanded on the device once the blob is there
+    struct BlockImage {
+        rdr_image_desc desc;
+        GpuImage image;
+    };
+    std::vector<BlockImage> block_images;
+    size_t append(const void* src, size_t bytes) { // src == nullptr: zero-filled
         const size_t off = (blob.size() + 255) & ~(size_t)255;
         blob.resize(off + bytes);
-        if (bytes) std::memcpy(blob.data() + off, src, bytes);
+        if (bytes && src) std::memcpy(blob.data() + off, src, bytes);
         return off;
     }
 };
@@ -265,14 +272,37 @@ struct TexelPacker {
 GpuImage pack_image(TexelPacker& tp, const rdr_image_desc& im) {
     GpuImage g{};
     if (!im.data) return g; // mip_count 0: samples as zero
-    g.width = im.width; g.height = im.height; g.mip_count = im.mip_count; g.format = im.format;
+    const bool blocks = im.format >= RDR_FORMAT_BC1;
+    g.width = im.width; g.height = im.height; g.mip_count = im.mip_count;
+    g.format = blocks ? RDR_FORMAT_RGBA8_UNORM : im.format;
     size_t bytes = 0;
     for (uint32_t l = 0; l < im.mip_count; ++l) {
         g.level_offset[l] = (uint32_t)bytes;
-        bytes += (size_t)mip_dim(im.width, l) * mip_dim(im.height, l) * texel_bytes(im.format);
+        bytes += (size_t)mip_dim(im.width, l) * mip_dim(im.height, l) * texel_bytes(g.format);
     }
-    g.offset = tp.append(im.data, bytes);
+    g.offset = tp.append(blocks ? nullptr : im.data, bytes);
+    if (blocks) tp.block_images.push_back({im, g});
     return g;
+}
+
+// Expands the block-compressed images into the places pack_image reserved in the uploaded blob.
+int decode_block_images(const TexelPacker& tp, uint8_t* texels_dev) {
+    for (const TexelPacker::BlockImage& b : tp.block_images) {
+        size_t total = 0;
+        for (uint32_t l = 0; l < b.desc.mip_count; ++l)
+            total += rdr_bc_level_bytes(b.desc.format, mip_dim(b.desc.width, l), mip_dim(b.desc.height, l));
+        DeviceBuffer<uint8_t> src;
+        if (src.upload(static_cast<const uint8_t*>(b.desc.data), total)) return 1;
+        size_t off = 0;
+        for (uint32_t l = 0; l < b.desc.mip_count; ++l) {
+            const uint32_t w = mip_dim(b.desc.width, l), h = mip_dim(b.desc.height, l);
+            uint32_t* out = reinterpret_cast<uint32_t*>(texels_dev + b.image.offset + b.image.level_offset[l]);
+            if (rdr_launch_decode_bc(b.desc.format, w, h, src.ptr + off, out, nullptr)) return 1;
+            off += rdr_bc_level_bytes(b.desc.format, w, h);
+        }
+        RDR_HIP(hipDeviceSynchronize()); // src is released at the end of the iteration
+    }
+    return 0;
 }
 
 int pack_cubemap(TexelPacker& tp, const rdr_cubemap_desc* cm, GpuCubemap* out) {
@@ -585,6 +615,7 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
         if (pack_cubemap(tp, s.env ? &s.env->skybox : nullptr, &r->sv.skybox)) return 1;
         if (r->images.upload(imgs.data(), imgs.size())) return 1;
         if (r->texels.upload(tp.blob.data(), tp.blob.size())) return 1;
+        if (decode_block_images(tp, r->texels.ptr)) return 1;
     }
 
     // shadow-ray structure

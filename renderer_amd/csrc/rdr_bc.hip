@@ -1,0 +1,181 @@
+// rdr_bc.hip — block-compressed textures (BC1, BC2, BC3, BC4 unorm) expanded to RGBA8 on the GPU
+// when a scene is uploaded.
+//
+// The reference hands the blocks of a .dds file to Vulkan unchanged
+// (renderer/src/renderer/image_loader.rs:63-135) and the sampler hardware decodes them; here the
+// sampler is software over RGBA8 texels, so the blocks are decoded once, at upload, and filtering
+// then sees exactly the texel values a block decoder produces.  The interpolated palette entries
+// follow the usual integer forms, rounded to nearest: (2a + b + 1) / 3 for colours, and
+// ((7 - i)a + ib + 3) / 7 or ((5 - i)a + ib + 2) / 5 for the single-channel ramp.
+#include <hip/hip_runtime.h>
+
+#include "rdr_internal.h"
+
+namespace {
+
+uint32_t level_dim(uint32_t d, uint32_t l) {
+    const uint32_t v = d >> l;
+    return v ? v : 1u;
+}
+
+struct Scratch { // device allocation released on every return path
+    void* ptr = nullptr;
+    ~Scratch() {
+        if (ptr) (void)hipFree(ptr);
+    }
+};
+
+__device__ inline uint32_t rgb565(uint32_t c) {
+    const uint32_t r = (c >> 11) & 31u, g = (c >> 5) & 63u, b = c & 31u;
+    return ((r << 3) | (r >> 2)) | (((g << 2) | (g >> 4)) << 8) | (((b << 3) | (b >> 2)) << 16);
+}
+
+__device__ inline uint32_t mix3(uint32_t a, uint32_t b) { // per channel (2a + b + 1) / 3
+    uint32_t out = 0;
+#pragma unroll
+    for (int s = 0; s < 24; s += 8) out |= ((2u * ((a >> s) & 255u) + ((b >> s) & 255u) + 1u) / 3u) << s;
+    return out;
+}
+
+__device__ inline uint32_t mix2(uint32_t a, uint32_t b) { // per channel (a + b) / 2
+    uint32_t out = 0;
+#pragma unroll
+    for (int s = 0; s < 24; s += 8) out |= ((((a >> s) & 255u) + ((b >> s) & 255u)) / 2u) << s;
+    return out;
+}
+
+// The colour half of a block: two RGB565 end points and sixteen 2-bit selectors.  `punch`: the
+// BC1 rule that c0 <= c1 means three colours plus transparent black.
+__device__ inline void color_block(const uint8_t* b, bool punch, uint32_t* px) {
+    const uint32_t c0 = b[0] | (b[1] << 8), c1 = b[2] | (b[3] << 8);
+    const uint32_t sel = b[4] | (b[5] << 8) | (b[6] << 16) | ((uint32_t)b[7] << 24);
+    uint32_t pal[4];
+    pal[0] = rgb565(c0) | 0xFF000000u;
+    pal[1] = rgb565(c1) | 0xFF000000u;
+    if (!punch || c0 > c1) {
+        pal[2] = mix3(pal[0], pal[1]) | 0xFF000000u;
+        pal[3] = mix3(pal[1], pal[0]) | 0xFF000000u;
+    } else {
+        pal[2] = mix2(pal[0], pal[1]) | 0xFF000000u;
+        pal[3] = 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) px[i] = pal[(sel >> (2 * i)) & 3u];
+}
+
+// The single-channel ramp of BC3's alpha and of BC4: two 8-bit end points, sixteen 3-bit selectors.
+__device__ inline void ramp_block(const uint8_t* b, uint32_t* v) {
+    const uint32_t a0 = b[0], a1 = b[1];
+    uint32_t pal[8];
+    pal[0] = a0; pal[1] = a1;
+    if (a0 > a1) {
+#pragma unroll
+        for (uint32_t i = 1; i < 7; ++i) pal[i + 1] = ((7u - i) * a0 + i * a1 + 3u) / 7u;
+    } else {
+#pragma unroll
+        for (uint32_t i = 1; i < 5; ++i) pal[i + 1] = ((5u - i) * a0 + i * a1 + 2u) / 5u;
+        pal[6] = 0u; pal[7] = 255u;
+    }
+    const unsigned long long sel = (unsigned long long)b[2] | ((unsigned long long)b[3] << 8) | ((unsigned long long)b[4] << 16) |
+                                   ((unsigned long long)b[5] << 24) | ((unsigned long long)b[6] << 32) | ((unsigned long long)b[7] << 40);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = pal[(sel >> (3 * i)) & 7u];
+}
+
+// One thread per 4x4 block; texels outside the level (levels smaller than a block) are dropped.
+__global__ __launch_bounds__(256) void k_decode_bc(uint32_t format, uint32_t width, uint32_t height, const uint8_t* blocks, uint32_t* out) {
+    const uint32_t nbx = (width + 3u) / 4u, nby = (height + 3u) / 4u;
+    const uint32_t bi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bi >= nbx * nby) return;
+    const uint32_t bx = bi % nbx, by = bi / nbx;
+    const uint32_t block_bytes = (format == RDR_FORMAT_BC1 || format == RDR_FORMAT_BC4) ? 8u : 16u;
+    const uint8_t* b = blocks + (size_t)bi * block_bytes;
+    uint32_t px[16];
+    if (format == RDR_FORMAT_BC1) {
+        color_block(b, true, px);
+    } else if (format == RDR_FORMAT_BC2) {
+        color_block(b + 8, false, px);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t a4 = (b[i >> 1] >> ((i & 1) * 4)) & 15u;
+            px[i] = (px[i] & 0x00FFFFFFu) | ((a4 * 17u) << 24);
+        }
+    } else if (format == RDR_FORMAT_BC3) {
+        uint32_t a[16];
+        color_block(b + 8, false, px);
+        ramp_block(b, a);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) px[i] = (px[i] & 0x00FFFFFFu) | (a[i] << 24);
+    } else { // BC4: red from the ramp, green = blue = 0, alpha = 1
+        uint32_t v[16];
+        ramp_block(b, v);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) px[i] = v[i] | 0xFF000000u;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+        const uint32_t y = by * 4u + j;
+        if (y >= height) break;
+        uint32_t* row = out + (size_t)y * width + bx * 4u;
+        if (bx * 4u + 3u < width && (width & 3u) == 0u) {
+            *reinterpret_cast<uint4*>(row) = make_uint4(px[j * 4], px[j * 4 + 1], px[j * 4 + 2], px[j * 4 + 3]);
+        } else {
+            for (uint32_t i = 0; i < 4 && bx * 4u + i < width; ++i) row[i] = px[j * 4 + i];
+        }
+    }
+}
+
+} // namespace
+
+size_t rdr_bc_level_bytes(uint32_t format, uint32_t width, uint32_t height) {
+    const size_t block_bytes = (format == RDR_FORMAT_BC1 || format == RDR_FORMAT_BC4) ? 8 : 16;
+    return (size_t)((width + 3u) / 4u) * ((height + 3u) / 4u) * block_bytes;
+}
+
+// Decodes one level: `blocks` and `out` are device pointers, `out` width * height RGBA8 texels,
+// 16-byte aligned when the width is a multiple of four.
+int rdr_launch_decode_bc(uint32_t format, uint32_t width, uint32_t height, const uint8_t* blocks, uint32_t* out, hipStream_t stream) {
+    RDR_CHECK(format >= RDR_FORMAT_BC1 && format <= RDR_FORMAT_BC4, "decode_bc: format is not a block-compressed one");
+    RDR_CHECK(width && height, "decode_bc: empty level");
+    const uint32_t n = ((width + 3u) / 4u) * ((height + 3u) / 4u);
+    hipLaunchKernelGGL(k_decode_bc, dim3((n + 255u) / 256u), dim3(256), 0, stream, format, width, height, blocks, out);
+    RDR_HIP(hipGetLastError());
+    return 0;
+}
+
+// C-ABI: a whole mip chain from host memory to host memory (tools, tests); the scene upload uses
+// the same kernel without the trip back.
+extern "C" int rdr_decode_bc(int device, uint32_t format, uint32_t width, uint32_t height, uint32_t mip_count, const void* blocks,
+                             size_t block_bytes, void* out_rgba8) {
+    RDR_CHECK(format >= RDR_FORMAT_BC1 && format <= RDR_FORMAT_BC4, "decode_bc: format must be RDR_FORMAT_BC1 .. RDR_FORMAT_BC4");
+    RDR_CHECK(blocks && out_rgba8, "decode_bc: null pointer");
+    RDR_CHECK(width && height && mip_count >= 1 && mip_count <= 17, "decode_bc: dimensions / mip count invalid");
+    size_t need = 0, padded = 0;
+    std::vector<size_t> at(mip_count); // every decoded level starts on a 16-byte boundary of its own
+    for (uint32_t l = 0; l < mip_count; ++l) {
+        const uint32_t w = level_dim(width, l), h = level_dim(height, l);
+        need += rdr_bc_level_bytes(format, w, h);
+        at[l] = padded;
+        padded += ((size_t)w * h + 3) & ~(size_t)3;
+    }
+    RDR_CHECK(block_bytes >= need, "decode_bc: block data shorter than the mip chain needs");
+    RDR_HIP(hipSetDevice(device));
+    Scratch src, dst;
+    RDR_HIP(hipMalloc(&src.ptr, need));
+    RDR_HIP(hipMalloc(&dst.ptr, padded * 4));
+    RDR_HIP(hipMemcpy(src.ptr, blocks, need, hipMemcpyHostToDevice));
+    size_t off = 0;
+    for (uint32_t l = 0; l < mip_count; ++l) {
+        const uint32_t w = level_dim(width, l), h = level_dim(height, l);
+        if (rdr_launch_decode_bc(format, w, h, static_cast<const uint8_t*>(src.ptr) + off, static_cast<uint32_t*>(dst.ptr) + at[l], nullptr)) return 1;
+        off += rdr_bc_level_bytes(format, w, h);
+    }
+    RDR_HIP(hipDeviceSynchronize());
+    uint32_t* o = static_cast<uint32_t*>(out_rgba8);
+    for (uint32_t l = 0; l < mip_count; ++l) {
+        const size_t n = (size_t)level_dim(width, l) * level_dim(height, l);
+        RDR_HIP(hipMemcpy(o, static_cast<uint32_t*>(dst.ptr) + at[l], n * 4, hipMemcpyDeviceToHost));
+        o += n;
+    }
+    return 0;
+}

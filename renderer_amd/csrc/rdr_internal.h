@@ -361,4 +361,6 @@ struct GeometryResidency {
 int rdr_geometry_residency(GeometryResidency* out);
 int rdr_launch_shadow(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev); // classify + shadow rays
 int rdr_launch_shade(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev);  // the above, then k_shade
+size_t rdr_bc_level_bytes(uint32_t format, uint32_t width, uint32_t height);
+int rdr_launch_decode_bc(uint32_t format, uint32_t width, uint32_t height, const uint8_t* blocks, uint32_t* out, hipStream_t stream);
 int rdr_launch_resolve(const SceneView& sv, const FrameView& fv, uint32_t* out_xy, hipStream_t stream);

@@ -2,10 +2,11 @@
 (scenery/src/scene.rs:62-232) with ``build_material`` (:346-577) and ``build_scene_mesh_draws``
 (:579-664), plus a small exporter used to test it.
 
-Differences from the reference, all upstream of the frame path: meshlets come from this
-package's greedy builder, not meshoptimizer (so IDs differ from the reference's; use
-``scene.bin`` for identical meshlets), one LOD per mesh (no simplifier), and missing tangents are
-derived from the uv gradients instead of mikktspace.  Everything else follows the reference:
+Differences from the reference, all upstream of the frame path: meshlets and the LOD chain come
+from this library's own mesh preparation (``rdr_mesh_build``: same limits and rules as the
+reference's use of meshoptimizer, different algorithms, so IDs differ from the reference's; use
+``scene.bin`` for identical meshlets), and missing tangents are derived from the uv gradients
+instead of mikktspace.  Everything else follows the reference:
 meshes are appended per (node, primitive) in breadth-first node order, one transform per node in
 depth-first order, images are indexed by *texture* index, loaded as a single mip level, sRGB iff
 the file path contains "basecolor" (renderer/src/renderer/image_loader.rs:47-51).
@@ -18,6 +19,7 @@ import struct
 import numpy as np
 
 from . import abi
+from .dds import DdsError, read_dds
 from .scene import Camera, Image, Scene
 
 _COMPONENT = {5120: np.int8, 5121: np.uint8, 5122: np.int16, 5123: np.uint16, 5125: np.uint32, 5126: np.float32}
@@ -322,9 +324,20 @@ def _load_texture_images(doc, base_dir):
             continue
         path = os.path.join(base_dir, uri)
         if path not in cache:
-            with PilImage.open(path) as im:
-                cache[path] = np.array(im.convert("RGBA"), np.uint8)
-        out.append(Image([cache[path]], srgb="basecolor" in path))
+            cache[path] = None
+            ext = os.path.splitext(path)[1].lower()
+            if ext in (".jpg", ".jpeg", ".png", ".dds"):
+                # a .dds file of the same name wins over a .jpg / .png (image_loader.rs:254-263);
+                # any failure to load it falls back to the named file
+                try:
+                    cache[path] = read_dds(os.path.splitext(path)[0] + ".dds")
+                except (OSError, DdsError):
+                    if ext == ".dds":
+                        raise
+            if cache[path] is None:
+                with PilImage.open(path) as im:
+                    cache[path] = Image([np.array(im.convert("RGBA"), np.uint8)], srgb="basecolor" in path)
+        out.append(cache[path])
     return out
 
 

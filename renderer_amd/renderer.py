@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "rdr_set_partition", "rdr_set_shade_rows", "rdr_visbuffer_device_ptr", "rdr_color_device_ptr",
     "rdr_set_stream", "rdr_sync", "rdr_read_visbuffer", "rdr_read_visbuffer_u64", "rdr_read_color",
     "rdr_get_stats", "rdr_build_ubo", "rdr_get_ubo", "rdr_destroy", "rdr_last_error",
-    "rdr_bake_brdf_lut", "rdr_bake_env_map", "rdr_mesh_build", "rdr_mesh_result", "rdr_mesh_free",
+    "rdr_bake_brdf_lut", "rdr_bake_env_map", "rdr_mesh_build", "rdr_mesh_result", "rdr_mesh_free", "rdr_decode_bc",
 ]
 
 _LIB = None
@@ -69,6 +69,7 @@ def load_library():
     L.rdr_mesh_result.argtypes = [vp, C.POINTER(abi.BuiltMesh)]
     L.rdr_mesh_free.argtypes = [vp]
     L.rdr_mesh_free.restype = None
+    L.rdr_decode_bc.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp]
     _LIB = L
     return L
 

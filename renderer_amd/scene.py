@@ -48,6 +48,22 @@ class Image:
 
 
 @dataclass
+class BlockImage:
+    """Block-compressed texture as a .dds file holds it: ``data`` is the mip chain's blocks (uint8),
+    ``format`` one of ``abi.FORMAT_BC1`` .. ``FORMAT_BC4``.  The library expands it to RGBA8 on the
+    GPU when the scene is uploaded."""
+    data: np.ndarray
+    width: int
+    height: int
+    mip_count: int
+    format: int
+
+    def level_bytes(self, level):
+        w, h = max(1, self.width >> level), max(1, self.height >> level)
+        return ((w + 3) // 4) * ((h + 3) // 4) * (8 if self.format in (abi.FORMAT_BC1, abi.FORMAT_BC4) else 16)
+
+
+@dataclass
 class Cubemap:
     """``mips[i]`` is (6, n, n, 4), faces in +X,-X,+Y,-Y,+Z,-Z order."""
     mips: list
@@ -207,6 +223,13 @@ class Scene:
             return a.ctypes.data_as(C.c_void_p) if a.size else None
 
         def image_desc(img):
+            if isinstance(img, BlockImage):
+                blob = np.ascontiguousarray(img.data, np.uint8).reshape(-1)
+                need = sum(img.level_bytes(l) for l in range(img.mip_count))
+                if blob.size < need:
+                    raise ValueError(f"block-compressed image holds {blob.size} bytes, its mip chain needs {need}")
+                keep.append(blob)
+                return abi.ImageDesc(blob.ctypes.data_as(C.c_void_p), img.width, img.height, img.mip_count, img.format)
             blob = np.concatenate([np.ascontiguousarray(m).reshape(-1).view(np.uint8) for m in img.mips])
             keep.append(blob)
             h, w = img.mips[0].shape[:2]

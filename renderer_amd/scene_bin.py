@@ -29,7 +29,7 @@ import struct
 import numpy as np
 
 from . import abi
-from .scene import Camera, Cubemap, EnvMap, Image, Scene
+from .scene import BlockImage, Camera, Cubemap, EnvMap, Image, Scene
 
 MAGIC = b"RDRSCN01"
 
@@ -48,6 +48,10 @@ def _write_image(f, img):
     if img is None:
         f.write(struct.pack("<4I", 0, 0, 0, 0))
         return
+    if isinstance(img, BlockImage):  # blocks verbatim
+        f.write(struct.pack("<4I", img.width, img.height, img.mip_count, img.format))
+        f.write(np.ascontiguousarray(img.data, np.uint8).reshape(-1)[:sum(img.level_bytes(l) for l in range(img.mip_count))].tobytes())
+        return
     h, w = img.mips[0].shape[:2]
     f.write(struct.pack("<4I", w, h, len(img.mips), _image_format(img)))
     for m in img.mips:
@@ -58,6 +62,10 @@ def _read_image(f):
     w, h, mips, fmt = struct.unpack("<4I", f.read(16))
     if w == 0:
         return None
+    if fmt >= abi.FORMAT_BC1:
+        img = BlockImage(np.zeros(0, np.uint8), w, h, mips, fmt)
+        img.data = np.frombuffer(f.read(sum(img.level_bytes(l) for l in range(mips))), np.uint8).copy()
+        return img
     dt = _texel_dtype(fmt)
     out = []
     for l in range(mips):
@@ -79,6 +87,10 @@ def _read_cube(f):
     n, mips, fmt = struct.unpack("<3I", f.read(12))
     if n == 0:
         return None
+    if fmt >= abi.FORMAT_BC1:
+        img = BlockImage(np.zeros(0, np.uint8), w, h, mips, fmt)
+        img.data = np.frombuffer(f.read(sum(img.level_bytes(l) for l in range(mips))), np.uint8).copy()
+        return img
     dt = _texel_dtype(fmt)
     out = []
     for l in range(mips):

@@ -1,0 +1,268 @@
+"""Block-compressed textures: the .dds reader (counterpart of PixelData::from_dds,
+renderer/src/renderer/image_loader.rs:63-135), the CPU decode of the oracle against hand-computed
+blocks, and the GPU decode (``rdr_decode_bc`` and the scene upload) against the oracle, bit for bit.
+
+Parity unpinned against the reference itself: it ships no compressed texture and no decoded image;
+the expected values below are worked out by hand from the block layouts."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from renderer_amd import abi
+from renderer_amd.dds import DdsError, read_dds, write_dds
+from renderer_amd.scene import BlockImage, Image
+
+BC = [abi.FORMAT_BC1, abi.FORMAT_BC2, abi.FORMAT_BC3, abi.FORMAT_BC4]
+
+
+def oracle_decode(oracle, img):
+    dims = [(max(1, img.height >> l), max(1, img.width >> l)) for l in range(img.mip_count)]
+    out = np.zeros(sum(h * w for h, w in dims) * 4, np.uint8)
+    blocks = np.ascontiguousarray(img.data, np.uint8)
+    assert oracle.lib().orc_decode_bc(img.format, img.width, img.height, img.mip_count,
+                                      blocks.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
+    mips, at = [], 0
+    for h, w in dims:
+        mips.append(out[at:at + h * w * 4].reshape(h, w, 4).copy())
+        at += h * w * 4
+    return mips
+
+
+def random_image(fmt, width, height, mips, seed):
+    img = BlockImage(np.zeros(0, np.uint8), width, height, mips, fmt)
+    n = sum(img.level_bytes(l) for l in range(mips))
+    img.data = np.random.default_rng(seed).integers(0, 256, n, dtype=np.uint8)  # every byte pattern is a valid block
+    return img
+
+
+def one_block(fmt, raw):
+    return BlockImage(np.frombuffer(bytes(raw), np.uint8).copy(), 4, 4, 1, fmt)
+
+
+# ---- hand-computed blocks -------------------------------------------------------------------
+
+def test_bc1_four_colour_block(oracle):
+    # c0 = pure red (0xF800) > c1 = pure blue (0x001F): palette red, blue, (2r+b)/3, (r+2b)/3
+    sel = sum((i % 4) << (2 * i) for i in range(16))  # every row: selectors 0, 1, 2, 3
+    px = oracle_decode(oracle, one_block(abi.FORMAT_BC1, struct.pack("<HHI", 0xF800, 0x001F, sel)))[0]
+    assert px[0, 0].tolist() == [255, 0, 0, 255]
+    assert px[0, 1].tolist() == [0, 0, 255, 255]
+    assert px[0, 2].tolist() == [170, 0, 85, 255]   # (2*255 + 0 + 1) // 3, (0 + 255 + 1) // 3
+    assert px[0, 3].tolist() == [85, 0, 170, 255]
+    assert np.array_equal(px[3], px[0])
+
+
+def test_bc1_punch_through_block(oracle):
+    # c0 <= c1: third entry is the midpoint, fourth is transparent black
+    sel = sum((i % 4) << (2 * i) for i in range(16))
+    px = oracle_decode(oracle, one_block(abi.FORMAT_BC1, struct.pack("<HHI", 0x001F, 0xF800, sel)))[0]
+    assert px[1, 0].tolist() == [0, 0, 255, 255]
+    assert px[1, 1].tolist() == [255, 0, 0, 255]
+    assert px[1, 2].tolist() == [127, 0, 127, 255]
+    assert px[1, 3].tolist() == [0, 0, 0, 0]
+
+
+def test_rgb565_expansion_replicates_the_high_bits(oracle):
+    c = (0b10101 << 11) | (0b101010 << 5) | 0b01010
+    px = oracle_decode(oracle, one_block(abi.FORMAT_BC1, struct.pack("<HHI", c, c, 0)))[0]
+    assert px[0, 0].tolist() == [0b10101101, 0b10101010, 0b01010010, 255]
+
+
+def test_bc2_explicit_alpha_and_no_punch_through(oracle):
+    alpha = bytes([0x10, 0x32, 0x54, 0x76, 0x98, 0xBA, 0xDC, 0xFE])  # texel i has alpha nibble i
+    sel = 0xFFFFFFFF  # selector 3 everywhere; c0 <= c1 must still give the 2/3 colour, not transparency
+    px = oracle_decode(oracle, one_block(abi.FORMAT_BC2, alpha + struct.pack("<HHI", 0x0000, 0xFFFF, sel)))[0]
+    assert px[..., 3].reshape(-1).tolist() == [i * 17 for i in range(16)]
+    assert px[0, 0, :3].tolist() == [170, 170, 170]
+
+
+def test_bc3_alpha_ramps(oracle):
+    def block(a0, a1):
+        sel = sum((i % 8) << (3 * i) for i in range(16))
+        return bytes([a0, a1]) + sel.to_bytes(6, "little") + struct.pack("<HHI", 0xFFFF, 0xFFFF, 0)
+    px = oracle_decode(oracle, one_block(abi.FORMAT_BC3, block(210, 0)))[0]  # a0 > a1: six interpolated values
+    assert px[..., 3].reshape(-1)[:8].tolist() == [210, 0, 180, 150, 120, 90, 60, 30]
+    px = oracle_decode(oracle, one_block(abi.FORMAT_BC3, block(0, 200)))[0]  # a0 <= a1: four, then 0 and 255
+    assert px[..., 3].reshape(-1)[:8].tolist() == [0, 200, 40, 80, 120, 160, 0, 255]
+    assert px[0, 0, :3].tolist() == [255, 255, 255]
+
+
+def test_bc4_is_red_only(oracle):
+    sel = sum((i % 8) << (3 * i) for i in range(16))
+    px = oracle_decode(oracle, one_block(abi.FORMAT_BC4, bytes([255, 3]) + sel.to_bytes(6, "little")))[0]
+    assert px[..., 0].reshape(-1)[:8].tolist() == [255, 3, 219, 183, 147, 111, 75, 39]
+    assert (px[..., 1] == 0).all() and (px[..., 2] == 0).all() and (px[..., 3] == 255).all()
+
+
+def test_partial_blocks_and_mip_chain_layout(oracle):
+    img = random_image(abi.FORMAT_BC3, 10, 6, 4, 1)  # levels 10x6, 5x3, 2x1, 1x1: 3x2, 2x1, 1, 1 blocks
+    assert [img.level_bytes(l) for l in range(4)] == [96, 32, 16, 16]
+    mips = oracle_decode(oracle, img)
+    assert [m.shape for m in mips] == [(6, 10, 4), (3, 5, 4), (1, 2, 4), (1, 1, 4)]
+    # level 1 decoded on its own must equal level 1 of the chain (levels are independent, tightly packed)
+    alone = BlockImage(img.data[96:128], 5, 3, 1, abi.FORMAT_BC3)
+    assert np.array_equal(oracle_decode(oracle, alone)[0], mips[1])
+
+
+# ---- the file format ------------------------------------------------------------------------
+
+@pytest.mark.parametrize("dx10", [False, True])
+@pytest.mark.parametrize("fmt", BC)
+def test_dds_round_trip(tmp_path, fmt, dx10):
+    img = random_image(fmt, 24, 12, 3, 5)
+    path = str(tmp_path / "t.dds")
+    write_dds(path, img, dx10=dx10)
+    back = read_dds(path)
+    assert (back.width, back.height, back.mip_count, back.format) == (24, 12, 3, fmt)
+    assert np.array_equal(back.data[:img.data.size], img.data)
+
+
+def test_dds_srgb_codes_are_bound_as_unorm_and_legacy_codes_map(tmp_path):
+    img = random_image(abi.FORMAT_BC1, 8, 8, 1, 2)
+    path = str(tmp_path / "t.dds")
+    write_dds(path, img, dx10=True)
+    raw = bytearray(open(path, "rb").read())
+    struct.pack_into("<I", raw, 128, 72)  # BC1_UNORM_SRGB
+    open(path, "wb").write(raw)
+    assert read_dds(path).format == abi.FORMAT_BC1
+    struct.pack_into("<I", raw, 128, 78)  # BC3_UNORM_SRGB; the data is too short for 16-byte blocks
+    open(path, "wb").write(raw)
+    with pytest.raises(DdsError, match="need 64"):
+        read_dds(path)
+    write_dds(path, random_image(abi.FORMAT_BC3, 8, 8, 1, 2))
+    raw = bytearray(open(path, "rb").read())
+    raw[84:88] = b"DXT4"
+    open(path, "wb").write(raw)
+    assert read_dds(path).format == abi.FORMAT_BC3
+
+
+def test_dds_errors(tmp_path):
+    path = str(tmp_path / "t.dds")
+    open(path, "wb").write(b"PNG " + b"\0" * 200)
+    with pytest.raises(DdsError, match="not a DDS"):
+        read_dds(path)
+    write_dds(path, random_image(abi.FORMAT_BC1, 8, 8, 1, 2), dx10=True)
+    raw = bytearray(open(path, "rb").read())
+    for code, name in ((98, "BC7_UNORM"), (83, "BC5_UNORM"), (95, "BC6H_UF16"), (81, "BC4_SNORM")):
+        struct.pack_into("<I", raw, 128, code)
+        open(path, "wb").write(raw)
+        with pytest.raises(DdsError, match=name):
+            read_dds(path)
+    struct.pack_into("<I", raw, 128, 28)  # R8G8B8A8_UNORM: the reference's "Format is not supported"
+    open(path, "wb").write(raw)
+    with pytest.raises(DdsError, match="not supported"):
+        read_dds(path)
+    struct.pack_into("<I", raw, 80, 0x40)  # pixel format without a four-character code
+    open(path, "wb").write(raw)
+    with pytest.raises(DdsError, match="doesn't have a format"):
+        read_dds(path)
+
+
+def test_scene_bin_keeps_blocks(tmp_path):
+    from renderer_amd import synth
+    from renderer_amd.scene_bin import load_scene_bin, save_scene_bin
+    sc = synth.make_triangle_scene([(0, 0, 5), (1, 0, 5), (0, 1, 5)])
+    img = random_image(abi.FORMAT_BC2, 16, 8, 2, 9)
+    sc.add_image(img)
+    path = str(tmp_path / "s.bin")
+    save_scene_bin(sc, path)
+    back = load_scene_bin(path).images[-1]
+    assert isinstance(back, BlockImage) and (back.width, back.height, back.mip_count, back.format) == (16, 8, 2, abi.FORMAT_BC2)
+    assert np.array_equal(back.data, img.data)
+
+
+def test_gltf_prefers_the_dds_next_to_a_png(tmp_path):
+    """image_loader.rs:254-263: for a .png / .jpg the loader first tries the same name with .dds."""
+    from renderer_amd import synth
+    from renderer_amd.gltf import load_gltf, save_gltf
+    sc = synth.make_triangle_scene([(0, 0, 5), (1, 0, 5), (0, 1, 5)])
+    tex = sc.add_image(synth.checker_texture(16, 2))
+    sc.materials = sc.materials[:0]
+    sc.add_material(albedo_texture=tex)
+    path = str(tmp_path / "s.gltf")
+    save_gltf(sc, path)
+    pngs = [f for f in os.listdir(tmp_path) if f.endswith(".png")]
+    assert len(pngs) == 1
+    assert isinstance(load_gltf(path).images[0], Image)
+    img = random_image(abi.FORMAT_BC1, 16, 16, 1, 4)
+    write_dds(str(tmp_path / (os.path.splitext(pngs[0])[0] + ".dds")), img)
+    got = load_gltf(path).images[0]
+    assert isinstance(got, BlockImage) and np.array_equal(got.data[:img.data.size], img.data)
+    # a .dds the library cannot decode falls back to the .png, as the reference's or_else does
+    raw = bytearray(open(str(tmp_path / (os.path.splitext(pngs[0])[0] + ".dds")), "rb").read())
+    raw[84:88] = b"ATI2"
+    open(str(tmp_path / (os.path.splitext(pngs[0])[0] + ".dds")), "wb").write(raw)
+    assert isinstance(load_gltf(path).images[0], Image)
+
+
+# ---- GPU ------------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", BC)
+@pytest.mark.parametrize("shape", [(64, 64, 7), (256, 128, 9), (20, 12, 3), (5, 7, 3), (1, 1, 1), (4, 4, 1)])
+def test_gpu_decode_matches_the_oracle(oracle, fmt, shape):
+    from renderer_amd import dds
+    img = random_image(fmt, *shape, seed=fmt * 100 + shape[0])
+    got = dds.decode(img).mips
+    want = oracle_decode(oracle, img)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+
+
+@pytest.mark.gpu
+def test_gpu_decode_rejects_bad_arguments():
+    from renderer_amd import RendererError, dds
+    img = random_image(abi.FORMAT_BC3, 16, 16, 2, 1)
+    img.data = img.data[:100]
+    with pytest.raises(RendererError, match="shorter"):
+        dds.decode(img)
+    with pytest.raises(RendererError, match="format"):
+        dds.decode(BlockImage(np.zeros(64, np.uint8), 4, 4, 1, abi.FORMAT_RGBA8_UNORM))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", [abi.FORMAT_BC1, abi.FORMAT_BC3])
+def test_scene_with_block_texture_renders_like_its_decoded_twin(oracle, fmt):
+    """An alpha-masked, textured quad whose albedo is block-compressed: the upload-time decode must
+    give the frame the decoded RGBA8 image gives, key for key and byte for byte, and the oracle
+    (fed the CPU-decoded texels) must agree within the shading tolerance."""
+    from renderer_amd import Renderer, RendererConfig
+    from helpers import fb_triangle_scene, psnr
+    W, H = 160, 120
+    rng = np.random.default_rng(7)
+    img = BlockImage(np.zeros(0, np.uint8), 32, 32, 6, fmt)
+    data = rng.integers(0, 256, sum(img.level_bytes(l) for l in range(6)), dtype=np.uint8)
+    img.data = data
+    tris = [((10, 10, 3.0), (10, 110, 5.0), (150, 110, 5.0)), ((10, 10, 3.0), (150, 110, 5.0), (150, 10, 3.0))]
+    mat = dict(albedo_texture=0, emissive_factor_alpha_cutoff=(0, 0, 0, 0.5))
+
+    def scene(image):
+        sc = fb_triangle_scene(tris, W, H, alpha_mode=1, material=mat, image=image)
+        sc.vertices["uv"][:, :2] = rng2.uniform(0, 3, (len(sc.vertices), 2)).astype(np.float32)
+        return sc
+    rng2 = np.random.default_rng(3)
+    sc_blocks = scene(img)
+    rng2 = np.random.default_rng(3)
+    sc_texels = scene(Image(oracle_decode(oracle, img), srgb=False))
+    conf = RendererConfig(cull_enabled=False)
+    out = []
+    for sc in (sc_blocks, sc_texels):
+        r = Renderer(W, H, conf)
+        r.set_scene(sc)
+        r.render()
+        out.append((r.read_visbuffer_u64(), r.read_color()))
+        r.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
+    o = oracle.OracleRenderer(W, H, conf)
+    o.set_scene(sc_texels)
+    ovis = o.render_visbuffer()
+    assert np.array_equal(ovis, out[0][0])
+    ocol = o.shade()
+    assert int(np.abs(ocol.astype(int) - out[0][1].astype(int)).max()) <= 2 and psnr(ocol, out[0][1]) >= 40.0
+    n_cov = int((ovis != np.uint64(abi.VIS_CLEAR)).sum())
+    assert 0 < n_cov < W * H  # the alpha test removed some of the quad, not all of it
