@@ -30,7 +30,7 @@ RDR_DEV float half_of(uint32_t w, bool hi) {
     return (float)__builtin_bit_cast(_Float16, (uint16_t)(hi ? (w >> 16) : (w & 0xFFFFu)));
 }
 
-RDR_DEV bool ray_box(uint32_t wx, uint32_t wy, uint32_t wz, const SlabRay& r, float tmin, float tmax) {
+RDR_DEV bool ray_box(uint32_t wx, uint32_t wy, uint32_t wz, const SlabRay& r, float tmin, float tmax, float& t_exit) {
     wx = __builtin_amdgcn_alignbit(wx, wx, r.rx);
     wy = __builtin_amdgcn_alignbit(wy, wy, r.ry);
     wz = __builtin_amdgcn_alignbit(wz, wz, r.rz);
@@ -39,6 +39,7 @@ RDR_DEV bool ray_box(uint32_t wx, uint32_t wy, uint32_t wz, const SlabRay& r, fl
     const float nz = fmaf(half_of(wz, false), r.inv_d.z, r.c_near.z), fz = fmaf(half_of(wz, true), r.inv_d.z, r.c_far.z);
     const float t_in = fmaxf(fmaxf(fmaxf(nx, ny), nz), tmin);
     const float t_out = fminf(fminf(fminf(fx, fy), fz), tmax);
+    t_exit = t_out;
     return t_in <= t_out;
 }
 
@@ -160,11 +161,19 @@ RDR_DEV bool shadow_any_hit(const SceneView& sv, uint32_t own_instance, vec3 o, 
             const uint32_t code[4] = {codes.x, codes.y, codes.z, codes.w};
             const uint32_t wx[4] = {bx.x, bx.y, bx.z, bx.w}, wy[4] = {by.x, by.y, by.z, by.w}, wz[4] = {bz.x, bz.y, bz.z, bz.w};
             cur = kBvhNone;
+            // Any hit ends the ray, so the order of the children is free: the one the ray leaves last goes
+            // first.  A ray that starts on a closed surface finds its blocker on the far side, and the
+            // boxes around its origin, which it cannot hit, are left for last (measured against the stored
+            // order: -5 %; nearest first: +7 % on the field, +35 % indoors; a full sort of the four gains nothing more).
+            float cur_exit = -1.0e30f;
 #pragma unroll
             for (int i = 0; i < kBvhWidth; ++i) {
-                const bool h = (code[i] != kBvhNone) & ray_box(wx[i], wy[i], wz[i], ray.slab, tmin, tmax);
-                st.push_if(h & (cur != kBvhNone), cur);
-                cur = h ? code[i] : cur;
+                float t_exit;
+                const bool h = (code[i] != kBvhNone) & ray_box(wx[i], wy[i], wz[i], ray.slab, tmin, tmax, t_exit);
+                const bool take = h & (t_exit >= cur_exit);
+                st.push_if(h & (cur != kBvhNone), take ? cur : code[i]);
+                cur = take ? code[i] : cur;
+                cur_exit = take ? t_exit : cur_exit;
             }
         }
         // not "else": a leaf that the node above just selected is tested in the same iteration
