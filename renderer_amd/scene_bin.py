@@ -1,8 +1,8 @@
 """``scene.bin``: a flat little-endian dump of exactly the arrays the renderer uploads
 (``SceneResources::load_scene``, renderer/src/renderer.rs:426-586), so that a scene loaded by
 the reference (glTF / .ptto through ``scenery``, meshlets built by meshoptimizer) can be handed
-to this path with identical meshlets and IDs.  A reference-side writer is ~30 lines after
-``Scene::load_*`` (shown in INTEGRATION.md); this module reads and writes the same bytes.
+to this path with identical meshlets and IDs.  A reference-side writer is about 30 lines of Rust after
+``Scene::load_*`` (one ``write_all`` per array below); this module reads and writes the same bytes.
 
 Layout (all integers little-endian u32 unless noted, no padding between sections):
 
