@@ -648,6 +648,7 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
     sv.material_count = s.material_count;
     sv.image_count = s.image_count;
     sv.meshlet_count = s.meshlet_count;
+    sv.masked_meshlets = (uint32_t)std::min<uint64_t>(masked_total, 0xFFFFFFFFull);
     sv.blas_tris = r->blas_tris.ptr;
     if (upload_tlas(r)) return 1;
     r->meshlet_visibility_count = s.meshlet_visibility_count;
@@ -714,7 +715,8 @@ int rdr_shade(rdr_renderer* r) {
     RDR_CHECK(r, "rdr_shade: renderer is null");
     RDR_CHECK(r->has_scene && r->frame_rendered, "rdr_shade: no visibility buffer rendered yet");
     RDR_HIP(hipSetDevice(r->device));
-    const FrameView fv = make_frame_view(r);
+    FrameView fv = make_frame_view(r);
+    fv.list_heads_zero = r->shaded ? 0u : 1u; // first shading pass over this visibility buffer
     hipEvent_t* ev = r->cfg.time_kernels ? r->ring.data() + (size_t)r->cur_slot * rdr_renderer::kEvents : nullptr;
     if (rdr_launch_shade(r->sv, fv, r->stream, ev)) return 1;
     r->shaded = true;

@@ -1496,8 +1496,10 @@ int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t st
     auto raster_lists = [&](const FrameView& f, hipEvent_t* mid_event) {
         // persistent grids: the work-list lengths live in device memory
         hipLaunchKernelGGL(k_raster<false>, dim3(f.grid.raster_blocks), dim3(64), 0, stream, sv, f);
-        hipLaunchKernelGGL(k_raster<true>, dim3(f.grid.raster_mask_blocks), dim3(64), 0, stream, sv, f);
-        hipLaunchKernelGGL(k_alpha_frag, dim3(f.grid.frag_blocks), dim3(256), 0, stream, sv, f);
+        if (sv.masked_meshlets) { // a scene without alpha-tested draws has nothing for these two (an empty launch costs 4-5 us)
+            hipLaunchKernelGGL(k_raster<true>, dim3(f.grid.raster_mask_blocks), dim3(64), 0, stream, sv, f);
+            hipLaunchKernelGGL(k_alpha_frag, dim3(f.grid.frag_blocks), dim3(256), 0, stream, sv, f);
+        }
         hipLaunchKernelGGL(k_mid_raster, dim3(f.grid.mid_blocks), dim3(256), 0, stream, sv, f);
         if (mid_event) (void)hipEventRecord(*mid_event, stream);
         hipLaunchKernelGGL(k_tile_setup, dim3(256), dim3(256), 0, stream, sv, f);

@@ -269,6 +269,7 @@ struct SceneView {
     const uint8_t* texels;
     const float* srgb_lut;
     uint32_t draw_count, material_count, image_count, meshlet_count;
+    uint32_t masked_meshlets; // meshlets of alpha-tested draws in the scene: 0 = their kernels are not launched
     // shadow-ray structure
     const BvhWide* bvh;  // every mesh's bottom-level nodes, then the top-level nodes
     uint32_t tlas_base;  // index of the top level's node 0 in `bvh`
@@ -321,6 +322,7 @@ struct FrameView {
     // for larger or clipped triangles) it goes to the tile path.
     uint32_t lane_max_pixels, mid_max_pixels;
     uint32_t skybox; // 1: uncovered pixels get the skybox (k_skybox) instead of the clear colour
+    uint32_t list_heads_zero; // host side: pixel_count / shadow_overflow are still as the geometry pass's clear left them
     // Two-phase occlusion culling (result-neutral): state kept from the previous frame and the
     // depth pyramid of the early phase.  Level l holds, per 2^(l+1) x 2^(l+1) pixel block, the
     // smallest (farthest) depth bits of the block's pixels; the last level is 1 x 1.

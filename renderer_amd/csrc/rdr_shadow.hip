@@ -329,7 +329,9 @@ int rdr_launch_shadow(const SceneView& sv, const FrameView& fv, hipStream_t stre
     // beyond the list's length exit on their first instruction
     const uint32_t list_blocks = (uint32_t)(((size_t)(fv.row_hi - fv.row_lo) * fv.width + 255u) / 256u);
     if (ev) RDR_HIP(hipEventRecord(ev[6], stream));
-    RDR_HIP(hipMemsetAsync(&fv.counters->pixel_count, 0, 2 * sizeof(uint32_t), stream)); // pixel_count, shadow_overflow
+    // pixel_count, shadow_overflow: zeroed by the geometry pass's clear; only a second shading pass over the
+    // same visibility buffer has to reset them (a memset between kernels is a 4 us kernel of its own)
+    if (!fv.list_heads_zero) RDR_HIP(hipMemsetAsync(&fv.counters->pixel_count, 0, 2 * sizeof(uint32_t), stream));
     hipLaunchKernelGGL(k_classify, tiles, dim3(256), 0, stream, fv);
     if (ev) RDR_HIP(hipEventRecord(ev[7], stream));
     hipLaunchKernelGGL(k_shadow, dim3(list_blocks), dim3(256), 0, stream, sv, fv);
