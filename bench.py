@@ -32,9 +32,11 @@ def algorithmic_bytes(st, width, height, draws):
     px = width * height
     cov = st["pixels_covered"]
     return {
-        "clear": px * 8,
+        # the clear kernel proper only zeroes list heads and tile counts: the 8 B per pixel of the visibility
+        # buffer are stored by extra workgroups of the meshlet cull launch and are charged there
+        "clear": (width // 64 + 1) * (height // 64 + 1) * 4 + 13000,
         "draw_cull": draws * (16 + 64 + 160) + st["commands"] * 32,
-        "meshlet_cull": st["commands"] * 32 + st["meshlets_tested"] * 32 + st["meshlets_visible"] * 16,
+        "meshlet_cull": st["commands"] * 32 + st["meshlets_tested"] * 32 + st["meshlets_visible"] * 16 + px * 8,
         "raster": st["meshlets_visible"] * (16 + 32) + st["vertices_transformed"] * (4 + 12)
                   + st["triangles_tested"] * 3 + st["fragments"] * 8,
         # classification: every key read once, a list entry per covered pixel, the clear colour elsewhere

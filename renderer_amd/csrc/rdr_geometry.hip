@@ -168,18 +168,42 @@ __global__ __launch_bounds__(256) void k_draw_cull(SceneView sv, FrameView fv) {
 // Meshlet cull: one wave per command, one lane per meshlet; the 16 waves of a
 // workgroup reserve their output slots with a single atomic.
 // ------------------------------------------------------------------------------
+// One workgroup's share of the visibility-buffer clear: 1024 threads, kClearPerThread 16-byte stores each,
+// consecutive threads on consecutive addresses.
+constexpr uint32_t kClearPerThread = 4;
+RDR_DEV void clear_visbuffer(const FrameView& fv, uint32_t block) {
+    const size_t n = (size_t)fv.width * fv.height;
+    const size_t base = (size_t)block * (1024u * kClearPerThread) + threadIdx.x;
+#pragma unroll
+    for (uint32_t k = 0; k < kClearPerThread; ++k) {
+        const size_t i = (base + (size_t)k * 1024u) * 2;
+        if (i + 1 < n) {
+            *reinterpret_cast<ulonglong2*>(fv.vis + i) = make_ulonglong2(RDR_VIS_CLEAR, RDR_VIS_CLEAR);
+        } else if (i < n) {
+            fv.vis[i] = RDR_VIS_CLEAR;
+        }
+    }
+}
+
 template <int PHASE>
 __global__ __launch_bounds__(1024) void k_meshlet_cull(SceneView sv, FrameView fv) {
     __shared__ uint32_t wave_count[16];
     __shared__ uint32_t wave_masked[16];
     __shared__ uint32_t wg_base[2];
+    // Workgroups past the culling grid clear the visibility buffer: nothing reads it before the rasterisers,
+    // and the culling grid (a few hundred workgroups waiting on dependent loads) leaves the machine idle
+    // enough that the 8 bytes per pixel go out underneath it instead of in a pass of their own.
+    if (blockIdx.x >= fv.grid.cull_blocks) {
+        clear_visbuffer(fv, blockIdx.x - fv.grid.cull_blocks);
+        return;
+    }
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
     const rdr_ubo& u = fv.ubo;
     const uint32_t cmd_count = min(fv.counters->cmd_count, fv.command_capacity);
 
     uint32_t st_tested = 0, st_visible = 0, st_tris = 0;
-    for (uint32_t c0 = blockIdx.x * 16u; c0 < cmd_count; c0 += gridDim.x * 16u) {
+    for (uint32_t c0 = blockIdx.x * 16u; c0 < cmd_count; c0 += fv.grid.cull_blocks * 16u) {
         const uint32_t ci = c0 + wave;
         bool accept = false;
         uint32_t draw_id = 0, first = 0, instance_first = 0, tri_count = 0, count = 0, masked = 0;
@@ -1488,9 +1512,14 @@ int rdr_geometry_residency(GeometryResidency* out) {
 
 int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev) {
     const size_t npx = (size_t)fv.width * fv.height;
-    const uint32_t clear_blocks = (uint32_t)((npx / 2 + 1 + 255) / 256);
+    // with draws, the visibility buffer is cleared by extra workgroups of the frame's first meshlet cull
+    const bool clear_in_cull = sv.draw_count != 0;
+    const uint32_t n_tiles = fv.tiles_x * fv.tiles_y;
+    const uint32_t clear_blocks = clear_in_cull ? (n_tiles + 255u) / 256u : (uint32_t)((npx / 2 + 1 + 255) / 256);
+    const uint32_t cull_clear_blocks = (uint32_t)((npx / 2 + 1 + 1024u * kClearPerThread - 1) / (1024u * kClearPerThread));
     if (ev) RDR_HIP(hipEventRecord(ev[0], stream));
-    hipLaunchKernelGGL(k_clear, dim3(clear_blocks), dim3(256), 0, stream, fv.vis, npx, fv.counters, fv.tile_count, fv.tiles_x * fv.tiles_y);
+    hipLaunchKernelGGL(k_clear, dim3(std::max(clear_blocks, 1u)), dim3(256), 0, stream, fv.vis, clear_in_cull ? (size_t)0 : npx, fv.counters,
+                       fv.tile_count, n_tiles);
     if (ev) RDR_HIP(hipEventRecord(ev[1], stream));
     // one pass of the rasterisers over the current work lists
     auto raster_lists = [&](const FrameView& f, hipEvent_t* mid_event) {
@@ -1511,7 +1540,7 @@ int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t st
     if (sv.draw_count && !fv.occlusion) {
         hipLaunchKernelGGL(k_draw_cull<kPhaseSingle>, dim3(fv.grid.draw_blocks), dim3(256), 0, stream, sv, fv);
         if (ev) RDR_HIP(hipEventRecord(ev[2], stream));
-        hipLaunchKernelGGL(k_meshlet_cull<kPhaseSingle>, dim3(fv.grid.cull_blocks), dim3(1024), 0, stream, sv, fv);
+        hipLaunchKernelGGL(k_meshlet_cull<kPhaseSingle>, dim3(fv.grid.cull_blocks + cull_clear_blocks), dim3(1024), 0, stream, sv, fv);
         if (ev) RDR_HIP(hipEventRecord(ev[3], stream));
         raster_lists(fv, ev ? &ev[4] : nullptr);
         if (ev) RDR_HIP(hipEventRecord(ev[5], stream));
@@ -1519,7 +1548,7 @@ int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t st
         // early phase: what last frame's late phase found visible (opaque draws only)
         hipLaunchKernelGGL(k_draw_cull<kPhaseEarly>, dim3(fv.grid.draw_blocks), dim3(256), 0, stream, sv, fv);
         if (ev) RDR_HIP(hipEventRecord(ev[2], stream));
-        hipLaunchKernelGGL(k_meshlet_cull<kPhaseEarly>, dim3(fv.grid.cull_blocks), dim3(1024), 0, stream, sv, fv);
+        hipLaunchKernelGGL(k_meshlet_cull<kPhaseEarly>, dim3(fv.grid.cull_blocks + cull_clear_blocks), dim3(1024), 0, stream, sv, fv);
         if (ev) RDR_HIP(hipEventRecord(ev[3], stream));
         raster_lists(fv, ev ? &ev[4] : nullptr);
         // pyramid of its depth, then everything else against the pyramid; timed with the tile path
