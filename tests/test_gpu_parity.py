@@ -359,3 +359,22 @@ def test_8k_properties_with_large_clipped_triangles():
         acc = np.minimum(acc, g.read_visbuffer_u64())
     assert np.array_equal(acc, full)
     g.close()
+
+
+def test_shading_the_same_visibility_buffer_twice_gives_the_same_image(oracle):
+    """The first shading pass after a geometry pass relies on the list heads the clear zeroed; a
+    second pass over the same visibility buffer has to reset them itself."""
+    sc = synth.make_field(40, 2, lods=1, alpha_fraction=0.3, with_env=True)
+    g = Renderer(320, 200, RendererConfig(cull_enabled=False))
+    g.set_scene(sc)
+    g.render()
+    first = g.read_color().copy()
+    covered_first = g.stats()["pixels_covered"]
+    g.shade()
+    assert np.array_equal(g.read_color(), first)
+    assert g.stats()["pixels_covered"] == covered_first
+    g.render_visbuffer()
+    g.shade()
+    g.shade()
+    assert np.array_equal(g.read_color(), first)
+    g.close()
