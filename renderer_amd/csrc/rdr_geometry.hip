@@ -713,8 +713,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : 1
                         const TriSetup<int32_t> ts = setup_triangle<int32_t>(fv, s0, s1, s2, cull_front);
                         if (ts.valid) {
                             const int npx = (ts.px1 - ts.px0 + 1) * (ts.py1 - ts.py0 + 1);
-                            defer = npx > (int)fv.mid_max_pixels;
-                            mid = !defer && npx > (int)(MASK ? min(fv.lane_max_pixels, kLaneMaxPixels) : fv.lane_max_pixels);
+                            if constexpr (MASK) {
+                                // anything a lane cannot enumerate goes to the set-up kernel of the tile path, which
+                                // hands the mid-sized ones on to k_mid_raster: the scan set-up with its uv planes
+                                // would cost this kernel a quarter of its occupancy
+                                defer = npx > (int)min(fv.lane_max_pixels, kLaneMaxPixels);
+                            } else {
+                                defer = npx > (int)fv.mid_max_pixels;
+                                mid = !defer && npx > (int)fv.lane_max_pixels;
+                            }
                             if (!defer && !mid) {
                                 if constexpr (MASK) {
                                     int32_t r01, r12, r20;
@@ -784,7 +791,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : 1
                 }
             }
             // mid-sized triangles: queue their scan set-up, slots reserved with one atomic per wave
-            {
+            if constexpr (!MASK) {
                 const unsigned long long mm = __ballot(mid);
                 if (mm) {
                     const int leader = __ffsll((long long)mm) - 1;
@@ -1063,7 +1070,7 @@ __global__ __launch_bounds__(256) void k_tile_setup(SceneView sv, FrameView fv) 
         const uint32_t di = base_i + lane;
         ClipVert poly[10], tmp[10];
         int n = 0;
-        bool cull_front = true, masked = false, alpha_draw = false;
+        bool cull_front = true, masked = false, alpha_draw = false, unclipped = false;
         uint32_t id = 0, draw_id = 0;
         if (di < count) {
             const DeferredTriangle* dt = &fv.deferred[di];
@@ -1082,6 +1089,7 @@ __global__ __launch_bounds__(256) void k_tile_setup(SceneView sv, FrameView fv) 
             const bool needs = vert_needs_clip(poly[0].x, poly[0].y, poly[0].z, poly[0].w) ||
                                vert_needs_clip(poly[1].x, poly[1].y, poly[1].z, poly[1].w) ||
                                vert_needs_clip(poly[2].x, poly[2].y, poly[2].z, poly[2].w);
+            unclipped = !needs;
             if (needs) {
                 // Sutherland-Hodgman against near + the four guard-band planes
                 for (int plane = 0; plane < 5 && n > 0; ++plane) {
@@ -1115,6 +1123,35 @@ __global__ __launch_bounds__(256) void k_tile_setup(SceneView sv, FrameView fv) 
                 ok = make_setup(fv, s0, sp, sn, cull_front, t, mk);
                 sp = sn;
             }
+            t.id = id; t.draw_id = draw_id; t.masked = (masked ? 1u : 0u) | (alpha_draw ? 2u : 0u);
+            // Alpha-tested triangles that k_raster<true> could not enumerate in a lane but that fit a wave
+            // (unclipped, small extent, box within the mid limit) are handed on to k_mid_raster, which runs
+            // after this kernel: same record, same queue as the opaque ones k_raster<false> queues itself.
+            bool to_mid = false;
+            if (ok && alpha_draw && unclipped) {
+                const int32_t ex = max(t.X0, max(t.X1, t.X2)) - min(t.X0, min(t.X1, t.X2));
+                const int32_t ey = max(t.Y0, max(t.Y1, t.Y2)) - min(t.Y0, min(t.Y1, t.Y2));
+                const uint32_t npx = ((uint32_t)t.px1 - t.px0 + 1u) * ((uint32_t)t.py1 - t.py0 + 1u);
+                to_mid = ex <= kSmallExtent && ey <= kSmallExtent && npx <= fv.mid_max_pixels;
+            }
+            const unsigned long long mm = __ballot(to_mid);
+            if (mm) {
+                const int mid_leader = __ffsll((long long)mm) - 1;
+                const uint32_t seg = blockIdx.x % kMidSegments, seg_capacity = fv.mid_capacity / kMidSegments;
+                uint32_t base = 0;
+                if ((int)lane == mid_leader) base = atomicAdd(&fv.counters->mid_seg[seg * 32u], (uint32_t)__popcll(mm));
+                base = __shfl(base, mid_leader, 64);
+                if (to_mid) {
+                    const uint32_t in_seg = base + ballot_rank(mm);
+                    if (in_seg < seg_capacity) {
+                        fv.mid[seg * seg_capacity + in_seg] = t;
+                        if (masked) fv.mid_mask[seg * seg_capacity + in_seg] = mk;
+                    } else {
+                        atomicAdd(&fv.counters->mid_overflow, 1u);
+                    }
+                }
+            }
+            ok = ok && !to_mid;
             const unsigned long long m = __ballot(ok);
             if (!m) continue;
             const int leader = __ffsll((long long)m) - 1;
@@ -1127,7 +1164,6 @@ __global__ __launch_bounds__(256) void k_tile_setup(SceneView sv, FrameView fv) 
                 atomicAdd(&fv.counters->setup_overflow, 1u);
                 continue;
             }
-            t.id = id; t.draw_id = draw_id; t.masked = (masked ? 1u : 0u) | (alpha_draw ? 2u : 0u);
             fv.setup[slot] = t;
             if (masked) fv.setup_mask[slot] = mk;
         }
@@ -1529,9 +1565,9 @@ int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t st
             hipLaunchKernelGGL(k_raster<true>, dim3(f.grid.raster_mask_blocks), dim3(64), 0, stream, sv, f);
             hipLaunchKernelGGL(k_alpha_frag, dim3(f.grid.frag_blocks), dim3(256), 0, stream, sv, f);
         }
+        hipLaunchKernelGGL(k_tile_setup, dim3(256), dim3(256), 0, stream, sv, f); // also feeds k_mid_raster
         hipLaunchKernelGGL(k_mid_raster, dim3(f.grid.mid_blocks), dim3(256), 0, stream, sv, f);
         if (mid_event) (void)hipEventRecord(*mid_event, stream);
-        hipLaunchKernelGGL(k_tile_setup, dim3(256), dim3(256), 0, stream, sv, f);
         hipLaunchKernelGGL(k_tile_bin<false>, dim3(512), dim3(256), 0, stream, f);
         hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, f);
         hipLaunchKernelGGL(k_tile_bin<true>, dim3(512), dim3(256), 0, stream, f);
