@@ -232,20 +232,23 @@ RDR_DEV vec3 pixel_world_position(const SceneView& sv, const rdr_ubo& u, uint32_
     return interp3(bary, mk3(w1.x, w1.y, w1.z), mk3(w2.x, w2.y, w2.z), mk3(w3.x, w3.y, w3.z));
 }
 
-// Pass 0: classification.  A workgroup owns a 64x64-pixel region as sixteen 16x16 blocks, each
-// wave an 8x8 sub-block.  Pixels with no geometry get the shading pass's clear colour here;
-// covered pixels are appended to a compact pixel list, which the two passes below run over
-// with full waves.  One atomic per workgroup reserves the region's span of the list (same-
-// address atomics serialise, so they are kept to a few thousand per frame); inside the span
-// the order is block-, wave-, lane-major, so 64 consecutive entries stay spatially close.
-constexpr uint32_t kClassifyRegion = 64;
+// Pass 0: classification.  A workgroup of sixteen waves owns a 128x128-pixel region as four 64x64
+// quadrants; a quadrant is sixteen 16x16 blocks, and each of its four waves takes an 8x8 sub-block of
+// every block.  Pixels with no geometry get the shading pass's clear colour here; covered pixels are
+// appended to a compact pixel list, which the two passes below run over with full waves.  One atomic
+// per workgroup reserves the region's span of the list: atomics that return a value serialise on their
+// address at about 10 ns each, so their number per frame is what bounds this kernel (64x64 regions,
+// 2040 atomics at 4K: 0.031 ms; 128x128: 510).  Inside the span the order is quadrant-, block-, wave-,
+// lane-major, so 64 consecutive entries stay spatially close.
+constexpr uint32_t kClassifyRegion = 128;
 
-__global__ __launch_bounds__(256) void k_classify(FrameView fv) {
-    __shared__ uint32_t wave_count[16 * 4];
+__global__ __launch_bounds__(1024) void k_classify(FrameView fv) {
+    __shared__ uint32_t wave_count[4 * 16 * 4]; // [quadrant][block][wave of the quadrant]
+    __shared__ uint32_t scan_total[4];
     __shared__ uint32_t wg_base;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t x0 = blockIdx.x * kClassifyRegion + (wave & 1u) * 8 + (lane & 7u);
-    const uint32_t y0 = fv.row_lo + blockIdx.y * kClassifyRegion + (wave >> 1) * 8 + (lane >> 3);
+    const uint32_t lane = threadIdx.x & 63u, wave = (threadIdx.x >> 6) & 3u, quad = threadIdx.x >> 8;
+    const uint32_t x0 = blockIdx.x * kClassifyRegion + (quad & 1u) * 64 + (wave & 1u) * 8 + (lane & 7u);
+    const uint32_t y0 = fv.row_lo + blockIdx.y * kClassifyRegion + (quad >> 1) * 64 + (wave >> 1) * 8 + (lane >> 3);
     uint32_t covered_bits = 0;
     uint32_t* color = reinterpret_cast<uint32_t*>(fv.color);
 #pragma unroll
@@ -258,15 +261,27 @@ __global__ __launch_bounds__(256) void k_classify(FrameView fv) {
             if (!covered) color[pi] = 0u; // the shading pass clears its target to (0,0,0,0)
         }
         const unsigned long long m = __ballot(covered);
-        if (lane == 0) wave_count[b * 4 + wave] = (uint32_t)__popcll(m);
+        if (lane == 0) wave_count[quad * 64 + b * 4 + wave] = (uint32_t)__popcll(m);
         covered_bits |= covered ? (1u << b) : 0u;
     }
     __syncthreads();
-    if (threadIdx.x < 64) { // exclusive prefix sum of the 64 (block, wave) counts
-        const uint32_t c = wave_count[threadIdx.x];
-        const uint32_t inc = wave_scan_inclusive(c, lane);
-        wave_count[threadIdx.x] = inc - c;
-        if (threadIdx.x == 63) wg_base = inc ? atomicAdd(&fv.counters->pixel_count, inc) : 0u;
+    // exclusive prefix sum of the 256 (quadrant, block, wave) counts: a wave per quadrant, then the four totals
+    uint32_t c = 0, inc = 0;
+    if (threadIdx.x < 256) {
+        c = wave_count[threadIdx.x];
+        inc = wave_scan_inclusive(c, lane);
+        if (lane == 63) scan_total[threadIdx.x >> 6] = inc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const uint32_t q = threadIdx.x >> 6;
+        const uint32_t t0 = scan_total[0], t1 = scan_total[1], t2 = scan_total[2], t3 = scan_total[3];
+        const uint32_t before = (q > 0 ? t0 : 0u) + (q > 1 ? t1 : 0u) + (q > 2 ? t2 : 0u);
+        wave_count[threadIdx.x] = before + inc - c;
+        if (threadIdx.x == 0) {
+            const uint32_t total = t0 + t1 + t2 + t3;
+            wg_base = total ? atomicAdd(&fv.counters->pixel_count, total) : 0u;
+        }
     }
     __syncthreads();
     const uint32_t base = wg_base;
@@ -276,7 +291,7 @@ __global__ __launch_bounds__(256) void k_classify(FrameView fv) {
         const unsigned long long m = __ballot(covered);
         if (covered) {
             const uint32_t ix = x0 + (b & 3u) * 16, iy = y0 + (b >> 2) * 16;
-            fv.pixel_list[base + wave_count[b * 4 + wave] + ballot_rank(m)] = iy * fv.width + ix;
+            fv.pixel_list[base + wave_count[quad * 64 + b * 4 + wave] + ballot_rank(m)] = iy * fv.width + ix;
         }
     }
 }
@@ -332,7 +347,7 @@ int rdr_launch_shadow(const SceneView& sv, const FrameView& fv, hipStream_t stre
     // pixel_count, shadow_overflow: zeroed by the geometry pass's clear; only a second shading pass over the
     // same visibility buffer has to reset them (a memset between kernels is a 4 us kernel of its own)
     if (!fv.list_heads_zero) RDR_HIP(hipMemsetAsync(&fv.counters->pixel_count, 0, 2 * sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(k_classify, tiles, dim3(256), 0, stream, fv);
+    hipLaunchKernelGGL(k_classify, tiles, dim3(1024), 0, stream, fv);
     if (ev) RDR_HIP(hipEventRecord(ev[7], stream));
     hipLaunchKernelGGL(k_shadow, dim3(list_blocks), dim3(256), 0, stream, sv, fv);
     hipLaunchKernelGGL(k_shadow_deep, dim3(512), dim3(256), 0, stream, sv, fv);
