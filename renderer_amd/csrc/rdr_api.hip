@@ -78,7 +78,7 @@ struct rdr_renderer {
     DeviceBuffer<SetupMask> setup_mask;
     DeviceBuffer<SetupTri> mid;
     DeviceBuffer<SetupMask> mid_mask;
-    DeviceBuffer<uint32_t> tile_count, tile_offset, tile_cursor, bin_entries;
+    DeviceBuffer<uint32_t> tile_count, tile_offset, tile_cursor, tile_list, bin_entries;
     DeviceBuffer<uint32_t> resolve_out;
     DeviceBuffer<float> srgb_lut;
     DeviceBuffer<uint8_t> shadow;
@@ -361,6 +361,7 @@ FrameView make_frame_view(rdr_renderer* r) {
     fv.tile_count = r->tile_count.ptr;
     fv.tile_offset = r->tile_offset.ptr;
     fv.tile_cursor = r->tile_cursor.ptr;
+    fv.tile_list = r->tile_list.ptr;
     fv.bin_entries = r->bin_entries.ptr;
     fv.setup_capacity = (uint32_t)r->setup.count;
     fv.mid = r->mid.ptr;
@@ -396,7 +397,8 @@ FrameView make_frame_view(rdr_renderer* r) {
     g.cull_blocks = std::max(1u, std::min((fv.command_capacity + 15u) / 16u, std::max(1u, r->resident.meshlet_cull)));
     g.raster_blocks = std::max(1u, std::min(fv.visible_capacity, std::max(1u, r->resident.raster)));
     g.raster_mask_blocks = std::max(1u, std::min(r->masked_meshlets, std::max(1u, r->resident.raster_mask)));
-    g.deferred_blocks = fv.tiles_x * fv.tiles_y; // one workgroup per 64x64 tile
+    // the tile rasteriser's workgroups take tiles from the list of non-empty ones: one resident round
+    g.deferred_blocks = std::max(1u, std::min(fv.tiles_x * fv.tiles_y, r->resident.tile_raster));
     g.mid_blocks = std::max(1u, r->resident.mid_raster);
     g.frag_blocks = r->masked_meshlets ? std::max(1u, r->resident.alpha_frag) : 1u;
     g.shade_blocks_x = (r->width + 15u) / 16u;
@@ -471,7 +473,7 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
     if (r->pyramid.alloc(npx / 2 + width + height + 64)) return 1; // sum over levels <= W*H/3 + W + H + levels
     {
         const size_t n_tiles = (size_t)((width + 63) / 64) * ((height + 63) / 64);
-        if (r->tile_count.alloc(n_tiles) || r->tile_offset.alloc(n_tiles) || r->tile_cursor.alloc(n_tiles)) return 1;
+        if (r->tile_count.alloc(n_tiles) || r->tile_offset.alloc(n_tiles) || r->tile_cursor.alloc(n_tiles) || r->tile_list.alloc(n_tiles)) return 1;
         RDR_HIP(hipMemset(r->tile_count.ptr, 0, n_tiles * 4));
     }
     RDR_HIP(hipMemset(r->counters.ptr, 0, sizeof(FrameCounters)));

@@ -26,7 +26,8 @@ namespace {
 constexpr float kGuardBand = 8.0f;
 constexpr int kSmallExtent = 64 * 256; // bounding boxes up to 64 px on a side stay in k_raster / k_mid_raster (int32 exact); see FrameView::lane_max_pixels
 constexpr int kTile = 64;              // screen tile of the binned path, pixels
-constexpr int kTileBatch = 64;         // triangle records staged in LDS per round
+constexpr int kTileBatch = 64;
+constexpr int kTileBlock = 2;          // k_tile_raster: a thread owns kTileBlock x kTileBlock pixels of the tile         // triangle records staged in LDS per round
 
 enum : int { kPhaseSingle = 0, kPhaseEarly = 1, kPhaseLate = 2 };
 
@@ -1223,53 +1224,83 @@ __global__ __launch_bounds__(256) void k_tile_bin(FrameView fv) {
     }
 }
 
+// Prefix sum of the per-tile counts -> bin offsets, and the list of tiles that have anything in their
+// bin (ascending), which is what k_tile_raster walks.  Both sums travel in one 64-bit value: entries in
+// the low 40 bits, non-empty tiles above.
 __global__ __launch_bounds__(1024) void k_tile_scan(FrameView fv) {
-    __shared__ uint32_t partial[1024];
+    __shared__ unsigned long long partial[1024];
     const uint32_t n_tiles = fv.tiles_x * fv.tiles_y;
     const uint32_t per = (n_tiles + 1023u) / 1024u;
     const uint32_t first = threadIdx.x * per, last = min(first + per, n_tiles);
-    uint32_t sum = 0;
-    for (uint32_t i = first; i < last; ++i) sum += fv.tile_count[i];
+    unsigned long long sum = 0;
+    for (uint32_t i = first; i < last; ++i) {
+        const uint32_t c = fv.tile_count[i];
+        sum += (unsigned long long)c + (c ? (1ull << 40) : 0ull);
+    }
     partial[threadIdx.x] = sum;
     __syncthreads();
     for (uint32_t o = 1; o < 1024; o <<= 1) { // inclusive Hillis-Steele scan
-        const uint32_t v = threadIdx.x >= o ? partial[threadIdx.x - o] : 0u;
+        const unsigned long long v = threadIdx.x >= o ? partial[threadIdx.x - o] : 0ull;
         __syncthreads();
         partial[threadIdx.x] += v;
         __syncthreads();
     }
-    uint32_t run = partial[threadIdx.x] - sum;
+    const unsigned long long before = partial[threadIdx.x] - sum;
+    uint32_t run = (uint32_t)(before & ((1ull << 40) - 1ull)), listed = (uint32_t)(before >> 40);
     for (uint32_t i = first; i < last; ++i) {
+        const uint32_t c = fv.tile_count[i];
         fv.tile_offset[i] = run;
         fv.tile_cursor[i] = 0u;
-        run += fv.tile_count[i];
+        if (c) fv.tile_list[listed++] = i;
+        run += c;
     }
     if (threadIdx.x == 1023) {
-        fv.counters->bin_total = partial[1023];
-        if (partial[1023] > fv.bin_capacity) fv.counters->bin_overflow = 1u;
+        const unsigned long long total = partial[1023] & ((1ull << 40) - 1ull);
+        fv.counters->bin_total = (uint32_t)min(total, 0xFFFFFFFFull);
+        fv.counters->tile_nonempty = (uint32_t)(partial[1023] >> 40);
+        fv.counters->tile_next = 0u;
+        if (total > fv.bin_capacity) fv.counters->bin_overflow = 1u;
     }
 }
 
-__global__ __launch_bounds__(256) void k_tile_raster(SceneView sv, FrameView fv) {
+// B: side of the pixel block a thread owns; (kTile / B)^2 threads per tile.  With B = 2 (sixteen waves per
+// tile) the slowest tile, one under many large alpha-tested triangles, takes a quarter of the time it
+// takes with 4x4 blocks and four waves, and that tile is the kernel's length (interior scene: tile path
+// 0.175 -> 0.127 ms).  The grid is one resident round over the list of non-empty tiles, so a frame with nothing
+// in the bins pays for one workgroup per CU, not for one per tile.
+template <int B>
+__global__ __launch_bounds__((kTile / B) * (kTile / B)) void k_tile_raster(SceneView sv, FrameView fv) {
+    constexpr int kSide = kTile / B, kWaves = kSide * kSide / 64;
     __shared__ SetupTri batch[kTileBatch];
     __shared__ uint32_t batch_index[kTileBatch];
-    __shared__ uint32_t wg_frags[4];
-    const uint32_t tile = blockIdx.x;
-    const uint32_t n_all = fv.tile_count[tile];
-    const uint32_t off = fv.tile_offset[tile];
-    const uint32_t n = off >= fv.bin_capacity ? 0u : min(n_all, fv.bin_capacity - off);
+    __shared__ uint32_t wg_frags[kWaves];
     uint32_t frags = 0;
-    if (n) {
+    const uint32_t n_listed = min(fv.counters->tile_nonempty, fv.tiles_x * fv.tiles_y);
+    // A workgroup's first tile is its own index; further ones are handed out by a counter, so that the
+    // workgroups that drew light tiles take more of them (tile costs differ by two orders of magnitude).
+    // A frame with empty bins touches no counter.
+    __shared__ uint32_t next_li;
+    for (uint32_t li = blockIdx.x; li < n_listed;) {
+        const uint32_t this_li = li;
+        __syncthreads(); // the previous tile is done with the batch and with next_li
+        if (threadIdx.x == 0) next_li = gridDim.x + atomicAdd(&fv.counters->tile_next, 1u);
+        __syncthreads();
+        li = next_li;
+        const uint32_t tile = fv.tile_list[this_li];
+        const uint32_t n_all = fv.tile_count[tile];
+        const uint32_t off = fv.tile_offset[tile];
+        const uint32_t n = off >= fv.bin_capacity ? 0u : min(n_all, fv.bin_capacity - off);
+        if (n == 0u) continue;
         const int tile_x0 = (int)(tile % fv.tiles_x) * kTile, tile_y0 = (int)(tile / fv.tiles_x) * kTile;
-        // this thread's 4x4 pixel block
-        const int bx0 = tile_x0 + (int)(threadIdx.x & 15u) * 4, by0 = tile_y0 + (int)(threadIdx.x >> 4) * 4;
+        // this thread's B x B pixel block
+        const int bx0 = tile_x0 + (int)(threadIdx.x % kSide) * B, by0 = tile_y0 + (int)(threadIdx.x / kSide) * B;
         const bool block_on_screen = bx0 < (int)fv.width && by0 < (int)fv.height;
-        unsigned long long keys[16];
-        uint32_t on_screen = 0; // bit j * 4 + i: pixel (bx0 + i, by0 + j) exists
+        unsigned long long keys[B * B];
+        uint32_t on_screen = 0; // bit j * B + i: pixel (bx0 + i, by0 + j) exists
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < B * B; ++k) {
             keys[k] = RDR_VIS_CLEAR;
-            on_screen |= (bx0 + (k & 3) < (int)fv.width && by0 + (k >> 2) < (int)fv.height) ? (1u << k) : 0u;
+            on_screen |= (bx0 + (k % B) < (int)fv.width && by0 + (k / B) < (int)fv.height) ? (1u << k) : 0u;
         }
 
         for (uint32_t b0 = 0; b0 < n; b0 += kTileBatch) {
@@ -1287,27 +1318,27 @@ __global__ __launch_bounds__(256) void k_tile_raster(SceneView sv, FrameView fv)
             if (!block_on_screen) continue;
             for (uint32_t k = 0; k < nb; ++k) {
                 const SetupTri& t = batch[k];
-                if ((int)t.px1 < bx0 || (int)t.px0 > bx0 + 3 || (int)t.py1 < by0 || (int)t.py0 > by0 + 3) continue;
+                if ((int)t.px1 < bx0 || (int)t.px0 > bx0 + (B - 1) || (int)t.py1 < by0 || (int)t.py0 > by0 + (B - 1)) continue;
                 const EdgeEq e01 = make_edge(t.X0, t.Y0, t.X1, t.Y1, bx0, by0); // weight of v2
                 const EdgeEq e12 = make_edge(t.X1, t.Y1, t.X2, t.Y2, bx0, by0); // weight of v0
                 const EdgeEq e20 = make_edge(t.X2, t.Y2, t.X0, t.Y0, bx0, by0); // weight of v1
-                if (edge_max(e01, 3, 3) + e01.bias < 0 || edge_max(e12, 3, 3) + e12.bias < 0 || edge_max(e20, 3, 3) + e20.bias < 0) continue;
+                if (edge_max(e01, B - 1, B - 1) + e01.bias < 0 || edge_max(e12, B - 1, B - 1) + e12.bias < 0 || edge_max(e20, B - 1, B - 1) + e20.bias < 0) continue;
                 const float z0 = t.z0, dz1 = t.dz1, dz2 = t.dz2, inv_area = t.inv_area;
                 const uint32_t id = t.id;
                 if (!(t.masked & 2u)) {
-                    // opaque: branch-free over the 16 pixels; the depth is evaluated everywhere and kept where covered
+                    // opaque: branch-free over the block's pixels; the depth is evaluated everywhere and kept where covered
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < B; ++j) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
+                        for (int i = 0; i < B; ++i) {
                             const long long v01 = e01.e + e01.ax * i + e01.by * j;
                             const long long v12 = e12.e + e12.ax * i + e12.by * j;
                             const long long v20 = e20.e + e20.ax * i + e20.by * j;
-                            const bool in = (((v01 + e01.bias) | (v12 + e12.bias) | (v20 + e20.bias)) >= 0) & ((on_screen >> (j * 4 + i)) & 1u);
+                            const bool in = (((v01 + e01.bias) | (v12 + e12.bias) | (v20 + e20.bias)) >= 0) & ((on_screen >> (j * B + i)) & 1u);
                             const float l1 = edge_to_float(v20) * inv_area, l2 = edge_to_float(v01) * inv_area;
                             const float z = clampf(fmaf(l2, dz2, fmaf(l1, dz1, z0)), 0.0f, 1.0f);
                             const unsigned long long key = ((unsigned long long)(0x7FFFFFFFu - __float_as_uint(z)) << 32) | (unsigned long long)id;
-                            keys[j * 4 + i] = (in && key < keys[j * 4 + i]) ? key : keys[j * 4 + i];
+                            keys[j * B + i] = (in && key < keys[j * B + i]) ? key : keys[j * B + i];
                             frags += in ? 1u : 0u;
                         }
                     }
@@ -1318,13 +1349,13 @@ __global__ __launch_bounds__(256) void k_tile_raster(SceneView sv, FrameView fv)
                 // alpha-tested: coverage of the block first, then the texture is consulted only where it matters
                 uint32_t cov = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < B; ++j) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < B; ++i) {
                         const long long v01 = e01.e + e01.ax * i + e01.by * j;
                         const long long v12 = e12.e + e12.ax * i + e12.by * j;
                         const long long v20 = e20.e + e20.ax * i + e20.by * j;
-                        cov |= (((v01 + e01.bias) | (v12 + e12.bias) | (v20 + e20.bias)) >= 0) ? (1u << (j * 4 + i)) : 0u;
+                        cov |= (((v01 + e01.bias) | (v12 + e12.bias) | (v20 + e20.bias)) >= 0) ? (1u << (j * B + i)) : 0u;
                     }
                 }
                 cov &= on_screen;
@@ -1337,11 +1368,11 @@ __global__ __launch_bounds__(256) void k_tile_raster(SceneView sv, FrameView fv)
                     b.u0 = mk->uv[1][0]; b.v0 = mk->uv[1][1]; b.u1 = mk->uv[1][2]; b.v1 = mk->uv[1][3];
                     c.u0 = mk->uv[2][0]; c.v0 = mk->uv[2][1]; c.u1 = mk->uv[2][2]; c.v1 = mk->uv[2][3];
                 }
-                // Perspective-correct uv on the block's 5 x 5 sample grid, a row at a time: a pixel's forward
-                // differences are its right and lower neighbours' own uv, so 25 evaluations serve 16 pixels.
+                // Perspective-correct uv on the block's (B + 1)^2 sample grid, a row at a time: a pixel's forward
+                // differences are its right and lower neighbours' own uv (25 evaluations serve 16 pixels at B = 4).
                 auto uv_row = [&](int j, float* ru, float* rv) {
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) {
+                    for (int i = 0; i <= B; ++i) {
                         float u, v;
                         persp_uv<long long>(a, b, c, e12.e + e12.ax * i + e12.by * j, e20.e + e20.ax * i + e20.by * j,
                                             e01.e + e01.ax * i + e01.by * j, at.uv_set, u, v);
@@ -1349,14 +1380,14 @@ __global__ __launch_bounds__(256) void k_tile_raster(SceneView sv, FrameView fv)
                         rv[i] = v * at.sy + at.oy;
                     }
                 };
-                float ru[5] = {}, rv[5] = {}, nu[5] = {}, nv[5] = {};
+                float ru[B + 1] = {}, rv[B + 1] = {}, nu[B + 1] = {}, nv[B + 1] = {};
                 if (textured) uv_row(0, ru, rv);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < B; ++j) {
                     if (textured) uv_row(j + 1, nu, nv);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (!((cov >> (j * 4 + i)) & 1u)) continue;
+                    for (int i = 0; i < B; ++i) {
+                        if (!((cov >> (j * B + i)) & 1u)) continue;
                         if (at.enabled) {
                             float alpha = 1.0f;
                             if (textured)
@@ -1369,24 +1400,24 @@ __global__ __launch_bounds__(256) void k_tile_raster(SceneView sv, FrameView fv)
                         const float l1 = edge_to_float(v20) * inv_area, l2 = edge_to_float(v01) * inv_area;
                         const float z = clampf(fmaf(l2, dz2, fmaf(l1, dz1, z0)), 0.0f, 1.0f);
                         const unsigned long long key = ((unsigned long long)(0x7FFFFFFFu - __float_as_uint(z)) << 32) | (unsigned long long)id;
-                        keys[j * 4 + i] = min(keys[j * 4 + i], key);
+                        keys[j * B + i] = min(keys[j * B + i], key);
                         frags++;
                     }
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) { ru[i] = nu[i]; rv[i] = nv[i]; }
+                    for (int i = 0; i <= B; ++i) { ru[i] = nu[i]; rv[i] = nv[i]; }
                 }
             }
         }
-        // merge the block into the visibility buffer: rows of 4 keys, 32 contiguous bytes each
+        // merge the block into the visibility buffer: rows of B keys, contiguous
         if (block_on_screen) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < B; ++j) {
                 if (by0 + j >= (int)fv.height) continue;
                 unsigned long long* row = fv.vis + (size_t)(by0 + j) * fv.width + bx0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < B; ++i) {
                     if (bx0 + i >= (int)fv.width) continue;
-                    const unsigned long long k = keys[j * 4 + i];
+                    const unsigned long long k = keys[j * B + i];
                     if (k != RDR_VIS_CLEAR && k < row[i]) row[i] = k;
                 }
             }
@@ -1396,7 +1427,11 @@ __global__ __launch_bounds__(256) void k_tile_raster(SceneView sv, FrameView fv)
         const uint32_t f = wave_sum(frags);
         if ((threadIdx.x & 63u) == 0) wg_frags[threadIdx.x >> 6] = f;
         __syncthreads();
-        if (threadIdx.x == 0) stat_store(fv, fv.grid.slot_deferred + blockIdx.x, wg_frags[0] + wg_frags[1] + wg_frags[2] + wg_frags[3]);
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
+            for (int w = 0; w < kWaves; ++w) total += wg_frags[w];
+            stat_store(fv, fv.grid.slot_deferred + blockIdx.x, total);
+        }
     }
 }
 
@@ -1543,6 +1578,8 @@ int rdr_geometry_residency(GeometryResidency* out) {
     out->mid_raster = (uint32_t)(n * cus);
     RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_alpha_frag, 256, 0));
     out->alpha_frag = (uint32_t)(n * cus);
+    RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tile_raster<kTileBlock>, (kTile / kTileBlock) * (kTile / kTileBlock), 0));
+    out->tile_raster = (uint32_t)(n * cus);
     return 0;
 }
 
@@ -1571,7 +1608,7 @@ int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t st
         hipLaunchKernelGGL(k_tile_bin<false>, dim3(512), dim3(256), 0, stream, f);
         hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, f);
         hipLaunchKernelGGL(k_tile_bin<true>, dim3(512), dim3(256), 0, stream, f);
-        hipLaunchKernelGGL(k_tile_raster, dim3(f.grid.deferred_blocks), dim3(256), 0, stream, sv, f);
+        hipLaunchKernelGGL(k_tile_raster<kTileBlock>, dim3(f.grid.deferred_blocks), dim3((kTile / kTileBlock) * (kTile / kTileBlock)), 0, stream, sv, f);
     };
     if (sv.draw_count && !fv.occlusion) {
         hipLaunchKernelGGL(k_draw_cull<kPhaseSingle>, dim3(fv.grid.draw_blocks), dim3(256), 0, stream, sv, fv);

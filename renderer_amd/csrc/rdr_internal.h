@@ -114,9 +114,10 @@ struct FrameCounters {
     uint32_t bin_total;       // tile-bin entries needed this frame
     uint32_t bin_overflow;
     uint32_t vis_mask_count;  // alpha-masked meshlets, stored from the back of `visible`
-    uint32_t _pad_mid;
+    uint32_t tile_nonempty;   // tiles with at least one bin entry this pass (length of tile_list)
     uint32_t mid_overflow;
-    uint32_t _pad0[3];
+    uint32_t tile_next;       // k_tile_raster: tiles of tile_list handed out beyond each workgroup's first
+    uint32_t _pad0[2];
     unsigned long long _pad1[16];
     // SetupTri records queued for k_mid_raster, per segment of the queue.  Every wave of k_raster
     // reserves its slots with an atomic that returns a value, and same-address atomics serialise
@@ -308,6 +309,7 @@ struct FrameView {
     uint32_t* tile_count;  // per tile: triangles binned
     uint32_t* tile_offset; // per tile: first entry in bin_entries
     uint32_t* tile_cursor; // per tile: fill cursor
+    uint32_t* tile_list;   // the tiles with a non-empty bin, ascending
     uint32_t* bin_entries; // SetupTri indices grouped by tile
     uint32_t setup_capacity, bin_capacity, tiles_x, tiles_y;
     SetupTri* mid;        // scan set-ups of mid-sized triangles (k_raster -> k_mid_raster)
@@ -358,7 +360,7 @@ void rdr_build_tlas(const rdr_scene_desc& s, const float* transforms, HostBvh& i
 // ---- kernel launchers (rdr_geometry.hip / rdr_shade.hip) ---------------------
 int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev);
 struct GeometryResidency {
-    uint32_t meshlet_cull, raster, raster_mask, mid_raster, alpha_frag; // resident workgroups on the whole device
+    uint32_t meshlet_cull, raster, raster_mask, mid_raster, alpha_frag, tile_raster; // resident workgroups on the whole device
 };
 int rdr_geometry_residency(GeometryResidency* out);
 int rdr_launch_shadow(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev); // classify + shadow rays
