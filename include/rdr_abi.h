@@ -356,7 +356,9 @@ int rdr_bake_env_map(int hip_device, const rdr_cubemap_desc* skybox, uint32_t di
 /* indices, relative error limit 0.1, stop at >= 95 % or empty; error =  */
 /* max(level error, previous level's) x mesh extent).  Same rules and    */
 /* limits as the reference; the algorithms are this library's own, so    */
-/* meshlet contents are not identical to meshoptimizer's.  No GPU needed. */
+/* meshlet contents are not identical to meshoptimizer's.  fast_mode is   */
+/* RendererConfig::fast_mode (scenery/src/lib.rs:11): index order for a   */
+/* 16-entry FIFO vertex cache instead of the score-driven one.  No GPU.   */
 /* ------------------------------------------------------------------ */
 typedef struct rdr_mesh_builder rdr_mesh_builder;
 typedef struct rdr_built_mesh { /* views into the builder, valid until rdr_mesh_free */
@@ -369,7 +371,7 @@ typedef struct rdr_built_mesh { /* views into the builder, valid until rdr_mesh_
     rdr_mesh mesh;                     /* offsets relative to these arrays (vertex_offset = index_offset = 0) */
 } rdr_built_mesh;
 int rdr_mesh_build(const rdr_vertex* vertices, uint32_t vertex_count, const uint32_t* indices, uint32_t index_count,
-                   uint32_t max_lods, rdr_mesh_builder** out);
+                   uint32_t max_lods, uint32_t fast_mode, rdr_mesh_builder** out);
 int rdr_mesh_result(const rdr_mesh_builder* b, rdr_built_mesh* out);
 void rdr_mesh_free(rdr_mesh_builder* b);
 

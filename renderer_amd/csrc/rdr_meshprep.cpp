@@ -127,6 +127,64 @@ void optimize_vertex_cache(std::vector<uint32_t>& idx, uint32_t nv) {
     idx.swap(out);
 }
 
+// ---- 2b. vertex cache ordering for a FIFO cache (the reference's fast mode) --------------------
+// Linear-time fanning: emit every remaining triangle around a vertex, then continue with the vertex
+// of that fan that will still be in a FIFO cache of `cache_size` entries after its own triangles are
+// emitted (the one that entered the cache longest ago among those); on a dead end fall back to the
+// most recently touched vertex that still has triangles, then to the next untouched one.
+void optimize_vertex_cache_fifo(std::vector<uint32_t>& idx, uint32_t nv, uint32_t cache_size) {
+    const uint32_t nt = (uint32_t)idx.size() / 3;
+    if (nt == 0) return;
+    std::vector<uint32_t> live(nv, 0), first(nv + 1, 0);
+    for (uint32_t i : idx) live[i]++;
+    for (uint32_t v = 0; v < nv; ++v) first[v + 1] = first[v] + live[v];
+    std::vector<uint32_t> fill(first.begin(), first.end() - 1), adj(idx.size());
+    for (uint32_t t = 0; t < nt; ++t)
+        for (int k = 0; k < 3; ++k) adj[fill[idx[t * 3 + k]]++] = t;
+    std::vector<uint32_t> stamp(nv, 0), dead_end, out, ring;
+    std::vector<uint8_t> done(nt, 0);
+    out.reserve(idx.size());
+    uint32_t now = cache_size + 1, cursor = 0;
+    int fan = (int)idx[0];
+    while (fan >= 0) {
+        ring.clear();
+        for (uint32_t a = first[fan]; a < first[fan + 1]; ++a) {
+            const uint32_t t = adj[a];
+            if (done[t]) continue;
+            done[t] = 1;
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t v = idx[t * 3 + k];
+                out.push_back(v);
+                dead_end.push_back(v);
+                ring.push_back(v);
+                live[v]--;
+                if (now - stamp[v] > cache_size) stamp[v] = now++;
+            }
+        }
+        int next = -1;
+        uint32_t best = 0;
+        for (uint32_t v : ring) {
+            if (live[v] == 0) continue;
+            uint32_t age = 0; // position in the cache once v's own triangles have gone through it
+            if (now - stamp[v] + 2 * live[v] <= cache_size) age = now - stamp[v];
+            if (next < 0 || age > best) { best = age; next = (int)v; }
+        }
+        if (next < 0) {
+            while (!dead_end.empty() && next < 0) {
+                const uint32_t v = dead_end.back();
+                dead_end.pop_back();
+                if (live[v] > 0) next = (int)v;
+            }
+            while (next < 0 && cursor < nv) {
+                if (live[cursor] > 0) next = (int)cursor;
+                else cursor++;
+            }
+        }
+        fan = next;
+    }
+    idx.swap(out);
+}
+
 // ---- 3. vertex fetch ordering: vertices in order of first use --------------------------------
 void optimize_vertex_fetch(std::vector<uint32_t>& idx, std::vector<rdr_vertex>& verts) {
     std::vector<uint32_t> remap(verts.size(), kNone);
@@ -510,7 +568,7 @@ struct rdr_mesh_builder {
 extern "C" {
 
 int rdr_mesh_build(const rdr_vertex* vertices, uint32_t vertex_count, const uint32_t* indices, uint32_t index_count,
-                   uint32_t max_lods, rdr_mesh_builder** out) {
+                   uint32_t max_lods, uint32_t fast_mode, rdr_mesh_builder** out) {
     RDR_CHECK(out, "rdr_mesh_build: out is null");
     *out = nullptr;
     RDR_CHECK(vertices && indices && vertex_count && index_count, "rdr_mesh_build: empty mesh");
@@ -520,7 +578,10 @@ int rdr_mesh_build(const rdr_vertex* vertices, uint32_t vertex_count, const uint
     std::unique_ptr<rdr_mesh_builder> b(new rdr_mesh_builder());
     b->indices.assign(indices, indices + index_count);
     dedupe(vertices, vertex_count, b->indices, b->vertices);
+    // scenery/src/mesh.rs:204-210: one ordering pass, then a second one whose kind the mode picks
     optimize_vertex_cache(b->indices, (uint32_t)b->vertices.size());
+    if (fast_mode) optimize_vertex_cache_fifo(b->indices, (uint32_t)b->vertices.size(), 16);
+    else optimize_vertex_cache(b->indices, (uint32_t)b->vertices.size());
     optimize_vertex_fetch(b->indices, b->vertices);
 
     rdr_mesh& mesh = b->mesh;
@@ -554,7 +615,8 @@ int rdr_mesh_build(const rdr_vertex* vertices, uint32_t vertex_count, const uint
         float error = 0.0f;
         std::vector<uint32_t> lod = simplify(b->indices, b->vertices, target - target % 3, 1e-1, &error);
         if (lod.size() >= (size_t)((double)b->indices.size() * 0.95) || lod.empty()) break;
-        optimize_vertex_cache(lod, (uint32_t)b->vertices.size());
+        if (fast_mode) optimize_vertex_cache_fifo(lod, (uint32_t)b->vertices.size(), 16); // scenery/src/mesh.rs:305-309
+        else optimize_vertex_cache(lod, (uint32_t)b->vertices.size());
         const uint32_t before = (uint32_t)b->set.meshlets.size();
         build_meshlets(lod, b->vertices, b->set);
         rdr_mesh_lod& L = mesh.lods[mesh.lod_count];

@@ -344,7 +344,7 @@ def _load_texture_images(doc, base_dir):
 # ---------------------------------------------------------------------------------------------
 # loader
 # ---------------------------------------------------------------------------------------------
-def load_gltf(path, env=None, max_lods=8):
+def load_gltf(path, env=None, max_lods=8, fast_mode=False):
     doc, bin_chunk = _read_container(path)
     base_dir = os.path.dirname(os.path.abspath(path))
     buffers = _load_buffers(doc, base_dir, bin_chunk)
@@ -380,7 +380,7 @@ def load_gltf(path, env=None, max_lods=8):
         if "mesh" in node:
             for pi, prim in enumerate(doc["meshes"][node["mesh"]]["primitives"]):
                 v, idx = _primitive_vertices(doc, buffers, prim)
-                prim_mesh[node["mesh"] * 16 + pi] = sc.append_mesh_auto(v, idx, max_lods)  # Geometry::append_mesh (scenery/src/scene.rs:210)
+                prim_mesh[node["mesh"] * 16 + pi] = sc.append_mesh_auto(v, idx, max_lods, fast_mode)  # Geometry::append_mesh (scenery/src/scene.rs:210)
     sc.materials = (np.stack([build_material(m) for m in doc.get("materials", [])]) if doc.get("materials")
                     else np.zeros(0, abi.MATERIAL))
     sc.images = _load_texture_images(doc, base_dir)

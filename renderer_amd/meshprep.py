@@ -30,12 +30,12 @@ class BuiltMesh:
         return np.concatenate(out) if out else np.zeros((0, 3), np.uint32)
 
 
-def build_mesh(vertices, indices, max_lods=8):
+def build_mesh(vertices, indices, max_lods=8, fast_mode=False):
     L = load_library()
     v = np.ascontiguousarray(vertices, abi.VERTEX)
     i = np.ascontiguousarray(indices, np.uint32).reshape(-1)
     handle = C.c_void_p()
-    if L.rdr_mesh_build(v.ctypes.data_as(C.c_void_p), len(v), i.ctypes.data_as(C.c_void_p), len(i), max_lods, C.byref(handle)):
+    if L.rdr_mesh_build(v.ctypes.data_as(C.c_void_p), len(v), i.ctypes.data_as(C.c_void_p), len(i), max_lods, 1 if fast_mode else 0, C.byref(handle)):
         raise RendererError(L.rdr_last_error().decode())
     try:
         r = abi.BuiltMesh()

@@ -52,12 +52,12 @@ def read_obj(path):
     return v, np.asarray(tris, np.uint32).reshape(-1)
 
 
-def load_obj(model_files, env=None, max_lods=8):
+def load_obj(model_files, env=None, max_lods=8, fast_mode=False):
     """``model_files``: one path or several separated by commas, as on the reference's command line."""
     sc = Scene()
     for name in [f for f in str(model_files).split(",") if f]:
         v, idx = read_obj(name)
-        sc.append_mesh_auto(v, idx, max_lods)
+        sc.append_mesh_auto(v, idx, max_lods, fast_mode)
     sc.add_material()
     sc.add_draw(0, mat4_trs(), 0, 0)
     sc.camera = Camera((0.0, 0.0, 2.0), (0.0, 0.0, 1.0))

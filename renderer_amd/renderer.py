@@ -65,7 +65,7 @@ def load_library():
     L.rdr_destroy.argtypes = [vp]
     L.rdr_destroy.restype = None
     L.rdr_last_error.restype = C.c_char_p
-    L.rdr_mesh_build.argtypes = [vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.rdr_mesh_build.argtypes = [vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(vp)]
     L.rdr_mesh_result.argtypes = [vp, C.POINTER(abi.BuiltMesh)]
     L.rdr_mesh_free.argtypes = [vp]
     L.rdr_mesh_free.restype = None

@@ -134,12 +134,13 @@ class Scene:
         self.meshes = np.concatenate([self.meshes, mesh.reshape(1)])
         return len(self.meshes) - 1
 
-    def append_mesh_auto(self, vertices, indices, max_lods=8):
+    def append_mesh_auto(self, vertices, indices, max_lods=8, fast_mode=False):
         """``Geometry::append_mesh`` (scenery/src/mesh.rs:197-349) from a raw triangle list: the
         library de-duplicates and reorders the vertices, builds the meshlets and simplifies the
-        LOD chain.  Returns the mesh index."""
+        LOD chain (``fast_mode``: the reference's ``RendererConfig::fast_mode``, a cheaper index ordering).
+        Returns the mesh index."""
         from .meshprep import build_mesh
-        b = build_mesh(vertices, indices, max_lods)
+        b = build_mesh(vertices, indices, max_lods, fast_mode)
         mesh = b.mesh.copy()
         mesh["vertex_offset"] = len(self.vertices)
         mesh["index_offset"] = len(self.indices)

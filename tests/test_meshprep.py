@@ -143,3 +143,36 @@ def test_scene_append_mesh_auto_offsets_compose(oracle):
         o.set_scene(sc)
         out.append(o.render_visbuffer().copy() >> np.uint64(32))  # depth half of the key
     assert np.array_equal(out[0], out[1])
+
+
+def _fifo_misses(indices, cache=16):
+    """Vertex transforms a FIFO post-transform cache of ``cache`` entries would do for this index order."""
+    fifo, misses = [], 0
+    for v in np.asarray(indices).reshape(-1).tolist():
+        if v not in fifo:
+            misses += 1
+            fifo.append(v)
+            if len(fifo) > cache:
+                fifo.pop(0)
+    return misses
+
+
+def test_fast_mode_orders_for_a_fifo_cache_and_keeps_the_mesh(sphere):
+    """RendererConfig::fast_mode (scenery/src/lib.rs:11, mesh.rs:206-210,305-309): the second ordering pass
+    targets a 16-entry FIFO cache.  Same triangles, same limits, every level still a valid chain, and the
+    order does what it is for: far fewer FIFO misses than the unordered list."""
+    v, idx, normal = sphere
+    rng = np.random.default_rng(0)
+    shuffled = np.asarray(idx).reshape(-1, 3)[rng.permutation(len(idx) // 3)].reshape(-1)
+    fast = build_mesh(v, shuffled, fast_mode=True)
+    assert _tri_keys(fast.vertices, fast.indices) == _tri_keys(v, idx)
+    assert _tri_keys(fast.vertices, fast.lod_triangles(0)) == _tri_keys(v, idx)
+    assert fast.meshlets["vertex_count"].max() <= 64 and fast.meshlets["triangle_count"].max() <= 124
+    assert int(fast.mesh["lod_count"]) == int(normal.mesh["lod_count"])
+    assert not np.array_equal(fast.indices, normal.indices)
+    n_tri = len(idx) // 3
+    assert _fifo_misses(fast.indices) < 0.8 * n_tri  # a good order needs about 0.6 - 0.7 transforms per triangle
+    assert _fifo_misses(fast.indices) < 0.5 * _fifo_misses(shuffled)
+    for li in range(1, int(fast.mesh["lod_count"])):
+        t = fast.lod_triangles(li)
+        assert len(t) and t.max() < len(fast.vertices)
