@@ -1245,7 +1245,33 @@ __global__ __launch_bounds__(256) void k_tile_bin(FrameView fv) {
             const SetupTri w = fv.setup[record]; // the same address in every lane: one broadcast load
             const uint32_t wx0 = w.px0 / kTile, wy0 = w.py0 / kTile, ww = w.px1 / kTile - wx0 + 1u;
             const uint32_t wn = ww * (w.py1 / kTile - wy0 + 1u);
-            for (uint32_t q = lane; q < wn; q += 64u) bin_visit<FILL>(fv, w, record, wx0 + q % ww, wy0 + q / ww);
+            // four tiles per lane and round: the fill's atomics return a value (the slot), and one round
+            // trip per 64 tiles was most of this kernel's length on records that span the screen
+            for (uint32_t q0 = lane; q0 < wn; q0 += 256u) {
+                bool touched[4];
+                uint32_t tiles[4], got[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t q = q0 + 64u * k;
+                    const uint32_t tx = wx0 + q % ww, ty = wy0 + q / ww;
+                    touched[k] = q < wn && tile_touched(w, tx, ty);
+                    tiles[k] = ty * fv.tiles_x + tx;
+                }
+                if (FILL) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) got[k] = touched[k] ? atomicAdd(&fv.tile_cursor[tiles[k]], 1u) : 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (!touched[k]) continue;
+                        const uint32_t slot = fv.tile_offset[tiles[k]] + got[k];
+                        if (slot < fv.bin_capacity) fv.bin_entries[slot] = record;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (touched[k]) atomicAdd(&fv.tile_count[tiles[k]], 1u);
+                }
+            }
         }
     }
 }
