@@ -78,7 +78,8 @@ struct rdr_renderer {
     DeviceBuffer<SetupMask> setup_mask;
     DeviceBuffer<SetupTri> mid;
     DeviceBuffer<SetupMask> mid_mask;
-    DeviceBuffer<uint32_t> tile_count, tile_offset, tile_cursor, tile_list, bin_entries;
+    DeviceBuffer<uint32_t> tile_count, tile_offset, tile_cursor, bin_entries;
+    DeviceBuffer<uint2> tile_list;
     DeviceBuffer<uint32_t> resolve_out;
     DeviceBuffer<float> srgb_lut;
     DeviceBuffer<uint8_t> shadow;
@@ -362,6 +363,7 @@ FrameView make_frame_view(rdr_renderer* r) {
     fv.tile_offset = r->tile_offset.ptr;
     fv.tile_cursor = r->tile_cursor.ptr;
     fv.tile_list = r->tile_list.ptr;
+    fv.tile_list_capacity = (uint32_t)r->tile_list.count;
     fv.bin_entries = r->bin_entries.ptr;
     fv.setup_capacity = (uint32_t)r->setup.count;
     fv.mid = r->mid.ptr;
@@ -473,7 +475,7 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
     if (r->pyramid.alloc(npx / 2 + width + height + 64)) return 1; // sum over levels <= W*H/3 + W + H + levels
     {
         const size_t n_tiles = (size_t)((width + 63) / 64) * ((height + 63) / 64);
-        if (r->tile_count.alloc(n_tiles) || r->tile_offset.alloc(n_tiles) || r->tile_cursor.alloc(n_tiles) || r->tile_list.alloc(n_tiles)) return 1;
+        if (r->tile_count.alloc(n_tiles) || r->tile_offset.alloc(n_tiles) || r->tile_cursor.alloc(n_tiles)) return 1;
         RDR_HIP(hipMemset(r->tile_count.ptr, 0, n_tiles * 4));
     }
     RDR_HIP(hipMemset(r->counters.ptr, 0, sizeof(FrameCounters)));
@@ -578,6 +580,8 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
         if (r->deferred.alloc(n_def) || r->setup.alloc(n_def + n_def / 2) || r->setup_mask.alloc(n_def + n_def / 2) ||
             r->mid.alloc(n_def) || r->mid_mask.alloc(n_def)) return 1;
         if (r->bin_entries.alloc(std::max<size_t>(n_def * 4, (size_t)1 << 22))) return 1;
+        // jobs of the tile rasteriser: at most one partly filled job per tile plus the full ones
+        if (r->tile_list.alloc(((size_t)r->tile_count.count + r->bin_entries.count / kTileJob + 1) * 4)) return 1; // x parts per tile
         // small alpha-tested triangles and their covered pixels (at most 16 each): every LOD-0 triangle of the
         // alpha-tested draws, capped like the lists above
         const size_t n_frag = (size_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)r->masked_meshlets * 124, 1u << 12), 1u << 22);

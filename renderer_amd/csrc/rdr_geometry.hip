@@ -27,6 +27,9 @@ constexpr float kGuardBand = 8.0f;
 constexpr int kSmallExtent = 64 * 256; // bounding boxes up to 64 px on a side stay in k_raster / k_mid_raster (int32 exact); see FrameView::lane_max_pixels
 constexpr int kTile = 64;              // screen tile of the binned path, pixels
 constexpr int kTileBatch = 64;
+constexpr int kTilePart = 32;           // k_tile_raster: a job covers a kTilePart x kTilePart piece of a tile
+constexpr uint32_t kTileParts = (kTile / kTilePart) * (kTile / kTilePart);
+static_assert(kTileParts <= kTileJob, "the part index travels in the low bits of the job's first record");
 constexpr int kTileBlock = 2;          // k_tile_raster: a thread owns kTileBlock x kTileBlock pixels of the tile         // triangle records staged in LDS per round
 
 enum : int { kPhaseSingle = 0, kPhaseEarly = 1, kPhaseLate = 2 };
@@ -1276,9 +1279,10 @@ __global__ __launch_bounds__(256) void k_tile_bin(FrameView fv) {
     }
 }
 
-// Prefix sum of the per-tile counts -> bin offsets, and the list of tiles that have anything in their
-// bin (ascending), which is what k_tile_raster walks.  Both sums travel in one 64-bit value: entries in
-// the low 40 bits, non-empty tiles above.
+// Prefix sum of the per-tile counts -> bin offsets, and the job list of k_tile_raster: a tile's bin is cut
+// into jobs of kTileJob records, so that a tile under many expensive (large, alpha-tested) triangles is
+// worked on by several workgroups instead of setting the kernel's length alone.  Both sums travel in one
+// 64-bit value: entries in the low 40 bits, jobs above.
 __global__ __launch_bounds__(1024) void k_tile_scan(FrameView fv) {
     __shared__ unsigned long long partial[1024];
     const uint32_t n_tiles = fv.tiles_x * fv.tiles_y;
@@ -1287,7 +1291,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(FrameView fv) {
     unsigned long long sum = 0;
     for (uint32_t i = first; i < last; ++i) {
         const uint32_t c = fv.tile_count[i];
-        sum += (unsigned long long)c + (c ? (1ull << 40) : 0ull);
+        sum += (unsigned long long)c + ((unsigned long long)((c + kTileJob - 1u) / kTileJob * kTileParts) << 40);
     }
     partial[threadIdx.x] = sum;
     __syncthreads();
@@ -1303,48 +1307,51 @@ __global__ __launch_bounds__(1024) void k_tile_scan(FrameView fv) {
         const uint32_t c = fv.tile_count[i];
         fv.tile_offset[i] = run;
         fv.tile_cursor[i] = 0u;
-        if (c) fv.tile_list[listed++] = i;
+        for (uint32_t r = 0; r < c; r += kTileJob)
+            for (uint32_t part = 0; part < kTileParts; ++part, ++listed)
+                if (listed < fv.tile_list_capacity) fv.tile_list[listed] = make_uint2(i, r | part); // kTileJob >= kTileParts: the low bits are free
         run += c;
     }
     if (threadIdx.x == 1023) {
         const unsigned long long total = partial[1023] & ((1ull << 40) - 1ull);
         fv.counters->bin_total = (uint32_t)min(total, 0xFFFFFFFFull);
-        fv.counters->tile_nonempty = (uint32_t)(partial[1023] >> 40);
-        fv.counters->tile_next = 0u;
+        fv.counters->tile_nonempty = (uint32_t)min(partial[1023] >> 40, (unsigned long long)fv.tile_list_capacity);
         if (total > fv.bin_capacity) fv.counters->bin_overflow = 1u;
     }
 }
 
-// B: side of the pixel block a thread owns; (kTile / B)^2 threads per tile.  With B = 2 (sixteen waves per
-// tile) the slowest tile, one under many large alpha-tested triangles, takes a quarter of the time it
-// takes with 4x4 blocks and four waves, and that tile is the kernel's length (interior scene: tile path
-// 0.175 -> 0.127 ms).  The grid is one resident round over the list of non-empty tiles, so a frame with nothing
-// in the bins pays for one workgroup per CU, not for one per tile.
+// A workgroup takes jobs: kTileJob records of one tile's bin over one kTilePart x kTilePart piece of the
+// tile, a thread owning B x B pixels of it.  Small jobs in a one-resident-round grid, because what a tile
+// costs is mostly the chain of dependent loads in front of the arithmetic (list -> count / offset -> bin ->
+// records ... -> keys), which only other workgroups on the same CU can hide, and because a tile under many
+// large alpha-tested triangles would otherwise set the kernel's length alone (interior scene: one
+// 256-thread workgroup per tile with 4 x 4 pixels per thread 0.175 ms for the tile path, this 0.128 ms).
+// A frame with empty bins pays for the resident round only.
 template <int B>
-__global__ __launch_bounds__((kTile / B) * (kTile / B)) void k_tile_raster(SceneView sv, FrameView fv) {
-    constexpr int kSide = kTile / B, kWaves = kSide * kSide / 64;
+__global__ __launch_bounds__((kTilePart / B) * (kTilePart / B)) void k_tile_raster(SceneView sv, FrameView fv) {
+    constexpr int kSide = kTilePart / B, kWaves = kSide * kSide / 64;
     __shared__ SetupTri batch[kTileBatch];
     __shared__ uint32_t batch_index[kTileBatch];
     __shared__ uint32_t wg_frags[kWaves];
+    static_assert(kTileJob <= kTileBatch, "a job is staged in one batch");
     uint32_t frags = 0;
-    const uint32_t n_listed = min(fv.counters->tile_nonempty, fv.tiles_x * fv.tiles_y);
-    // A workgroup's first tile is its own index; further ones are handed out by a counter, so that the
-    // workgroups that drew light tiles take more of them (tile costs differ by two orders of magnitude).
-    // A frame with empty bins touches no counter.
-    __shared__ uint32_t next_li;
-    for (uint32_t li = blockIdx.x; li < n_listed;) {
-        const uint32_t this_li = li;
-        __syncthreads(); // the previous tile is done with the batch and with next_li
-        if (threadIdx.x == 0) next_li = gridDim.x + atomicAdd(&fv.counters->tile_next, 1u);
-        __syncthreads();
-        li = next_li;
-        const uint32_t tile = fv.tile_list[this_li];
+    const uint32_t n_listed = min(fv.counters->tile_nonempty, fv.tile_list_capacity);
+    // Jobs are dealt out by index, a grid's width apart: a shared counter would cost an atomic that returns a
+    // value per job, and those serialise on their address (10 000 jobs: 0.1 ms).
+    for (uint32_t this_li = blockIdx.x; this_li < n_listed; this_li += gridDim.x) {
+        const uint2 job = fv.tile_list[this_li];
+        const uint32_t tile = job.x;
         const uint32_t n_all = fv.tile_count[tile];
-        const uint32_t off = fv.tile_offset[tile];
-        const uint32_t n = off >= fv.bin_capacity ? 0u : min(n_all, fv.bin_capacity - off);
+        const uint32_t tile_off = fv.tile_offset[tile];
+        const uint32_t n_tile = tile_off >= fv.bin_capacity ? 0u : min(n_all, fv.bin_capacity - tile_off); // records that made it into the bin
+        const uint32_t first = job.y & ~(kTileJob - 1u), part = job.y & (kTileJob - 1u);
+        const uint32_t off = tile_off + first;
+        const uint32_t n = first < n_tile ? min(kTileJob, n_tile - first) : 0u;
+        const bool shared_tile = n_all > kTileJob; // other jobs work on the same pixels: merge with atomics
         if (n == 0u) continue;
-        const int tile_x0 = (int)(tile % fv.tiles_x) * kTile, tile_y0 = (int)(tile / fv.tiles_x) * kTile;
-        // this thread's B x B pixel block
+        // the job's part of the tile, and this thread's B x B pixel block in it
+        const int tile_x0 = (int)(tile % fv.tiles_x) * kTile + (int)(part % (kTile / kTilePart)) * kTilePart;
+        const int tile_y0 = (int)(tile / fv.tiles_x) * kTile + (int)(part / (kTile / kTilePart)) * kTilePart;
         const int bx0 = tile_x0 + (int)(threadIdx.x % kSide) * B, by0 = tile_y0 + (int)(threadIdx.x / kSide) * B;
         const bool block_on_screen = bx0 < (int)fv.width && by0 < (int)fv.height;
         unsigned long long keys[B * B];
@@ -1470,7 +1477,9 @@ __global__ __launch_bounds__((kTile / B) * (kTile / B)) void k_tile_raster(Scene
                 for (int i = 0; i < B; ++i) {
                     if (bx0 + i >= (int)fv.width) continue;
                     const unsigned long long k = keys[j * B + i];
-                    if (k != RDR_VIS_CLEAR && k < row[i]) row[i] = k;
+                    if (k == RDR_VIS_CLEAR) continue;
+                    if (shared_tile) atomicMin(&row[i], k);
+                    else if (k < row[i]) row[i] = k;
                 }
             }
         }
@@ -1630,7 +1639,7 @@ int rdr_geometry_residency(GeometryResidency* out) {
     out->mid_raster = (uint32_t)(n * cus);
     RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_alpha_frag, 256, 0));
     out->alpha_frag = (uint32_t)(n * cus);
-    RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tile_raster<kTileBlock>, (kTile / kTileBlock) * (kTile / kTileBlock), 0));
+    RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tile_raster<kTileBlock>, (kTilePart / kTileBlock) * (kTilePart / kTileBlock), 0));
     out->tile_raster = (uint32_t)(n * cus);
     return 0;
 }
@@ -1660,7 +1669,7 @@ int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t st
         hipLaunchKernelGGL(k_tile_bin<false>, dim3(512), dim3(256), 0, stream, f);
         hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, f);
         hipLaunchKernelGGL(k_tile_bin<true>, dim3(512), dim3(256), 0, stream, f);
-        hipLaunchKernelGGL(k_tile_raster<kTileBlock>, dim3(f.grid.deferred_blocks), dim3((kTile / kTileBlock) * (kTile / kTileBlock)), 0, stream, sv, f);
+        hipLaunchKernelGGL(k_tile_raster<kTileBlock>, dim3(f.grid.deferred_blocks), dim3((kTilePart / kTileBlock) * (kTilePart / kTileBlock)), 0, stream, sv, f);
     };
     if (sv.draw_count && !fv.occlusion) {
         hipLaunchKernelGGL(k_draw_cull<kPhaseSingle>, dim3(fv.grid.draw_blocks), dim3(256), 0, stream, sv, fv);

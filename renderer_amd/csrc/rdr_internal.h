@@ -114,10 +114,9 @@ struct FrameCounters {
     uint32_t bin_total;       // tile-bin entries needed this frame
     uint32_t bin_overflow;
     uint32_t vis_mask_count;  // alpha-masked meshlets, stored from the back of `visible`
-    uint32_t tile_nonempty;   // tiles with at least one bin entry this pass (length of tile_list)
+    uint32_t tile_nonempty;   // jobs of the tile rasteriser this pass (length of tile_list)
     uint32_t mid_overflow;
-    uint32_t tile_next;       // k_tile_raster: tiles of tile_list handed out beyond each workgroup's first
-    uint32_t _pad0[2];
+    uint32_t _pad0[3];
     unsigned long long _pad1[16];
     // SetupTri records queued for k_mid_raster, per segment of the queue.  Every wave of k_raster
     // reserves its slots with an atomic that returns a value, and same-address atomics serialise
@@ -131,6 +130,7 @@ struct FrameCounters {
     uint32_t frag_overflow;
     uint32_t _pad_frag[31];
 };
+constexpr uint32_t kTileJob = 8; // bin records per job of the tile rasteriser
 constexpr uint32_t kMidSegments = 32;
 constexpr uint32_t kFragSegments = 32;
 static_assert(sizeof(FrameCounters) == 192 + 4096 + 8192 + 128, "FrameCounters layout");
@@ -309,7 +309,8 @@ struct FrameView {
     uint32_t* tile_count;  // per tile: triangles binned
     uint32_t* tile_offset; // per tile: first entry in bin_entries
     uint32_t* tile_cursor; // per tile: fill cursor
-    uint32_t* tile_list;   // the tiles with a non-empty bin, ascending
+    uint2* tile_list;      // the tile rasteriser's jobs: (tile, first record of its bin), kTileJob records each
+    uint32_t tile_list_capacity;
     uint32_t* bin_entries; // SetupTri indices grouped by tile
     uint32_t setup_capacity, bin_capacity, tiles_x, tiles_y;
     SetupTri* mid;        // scan set-ups of mid-sized triangles (k_raster -> k_mid_raster)
