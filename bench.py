@@ -147,6 +147,11 @@ def main():
                     help="run the composite / gather collectives even with one rank (rehearsal)")
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line: native libraries write to file descriptor 1 on their own (RCCL's
+    # version banner, gloo's connection messages), so everything but that line is sent to stderr
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -290,7 +295,8 @@ def main():
                                    "kind": "port", "frames_per_s": 1.0 / dt,
                                    "sample": f"{args.cpu_frames} full frames of the same workload "
                                              "(CPU restatement of the reference path, OpenMP; not lavapipe)"}
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if frame is not None:
         frame.close()
     else:
