@@ -240,12 +240,14 @@ def main():
             ab_dom, t_dom = ab[dom], kms[dom]
         achieved = ab_dom / (t_dom * 1e-3) / 1e9 if t_dom > 0 else 0.0
         traffic = None
+        issue = None  # how busy the dominant kernel keeps the vector ALUs (from the same PMC record)
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
                 if rec.get("workload") == [args.instances, args.subdivisions, W, H] and world == 1:
                     traffic = rec.get("kernels", {}).get(dom)
+                    issue = rec.get("issue", {}).get(dom)
             except Exception:
                 traffic = None
         out = {
@@ -280,7 +282,9 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes": ab_dom, "kernel_ms": t_dom,
                          "frame_algorithmic_bytes": sum(ab.values()),
-                         "frame_frac": sum(ab.values()) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "frame_frac": sum(ab.values()) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         # not memory-bound: what it is bound by instead (PMC passes of profiles/pmc_passes.sh)
+                         "valu_issue": issue},
         }
         raster_s = (kms["raster"] + kms["big_raster"]) * 1e-3
         if raster_s > 0:  # the rasteriser's own roofline is the L2 atomic rate (per-lane and per-wave scans issue one per fragment)
