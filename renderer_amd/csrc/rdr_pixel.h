@@ -11,32 +11,54 @@ struct BaryDeriv {
     vec3 lambda, ddx, ddy;
 };
 
+// Correctly rounded a / b whatever the file's division mode.  The shading file is built with the
+// approximate fp32 division, which is fine for the BRDF but not here: the barycentrics of a triangle many
+// screens large cancel catastrophically and turn a last-bit difference in 1 / w into a few per cent of colour.
+// This is the hardware's own IEEE sequence (scale, reciprocal, two Newton steps, residual, fix-up).
+#ifdef RDR_FAST_DIVISION
+RDR_DEV float div_exact(float a, float b) {
+    bool scaled_d, scaled_n;
+    const float d = __builtin_amdgcn_div_scalef(a, b, false, &scaled_d);
+    const float n = __builtin_amdgcn_div_scalef(a, b, true, &scaled_n);
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e0 = fmaf(-d, r, 1.0f);
+    r = fmaf(e0, r, r);
+    float q = n * r;
+    const float e1 = fmaf(-d, q, n);
+    q = fmaf(e1, r, q);
+    const float e2 = fmaf(-d, q, n);
+    return __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(e2, r, q, scaled_n), b, a);
+}
+#else
+RDR_DEV float div_exact(float a, float b) { return a / b; }
+#endif
+
 RDR_DEV BaryDeriv calc_full_bary(vec4 pt0, vec4 pt1, vec4 pt2, float ndcx, float ndcy, float winw, float winh) {
     BaryDeriv r;
-    const vec3 inv_w = mk3(1.0f / pt0.w, 1.0f / pt1.w, 1.0f / pt2.w);
+    const vec3 inv_w = mk3(div_exact(1.0f, pt0.w), div_exact(1.0f, pt1.w), div_exact(1.0f, pt2.w));
     const float n0x = pt0.x * inv_w.x, n0y = pt0.y * inv_w.x;
     const float n1x = pt1.x * inv_w.y, n1y = pt1.y * inv_w.y;
     const float n2x = pt2.x * inv_w.z, n2y = pt2.y * inv_w.z;
     const float ax = n2x - n1x, ay = n2y - n1y, bx = n0x - n1x, by = n0y - n1y;
-    const float inv_det = 1.0f / (ax * by - bx * ay);
+    const float inv_det = div_exact(1.0f, ax * by - bx * ay);
     r.ddx = (mk3(n1y - n2y, n2y - n0y, n0y - n1y) * inv_det) * inv_w;
     r.ddy = (mk3(n2x - n1x, n0x - n2x, n1x - n0x) * inv_det) * inv_w;
     float ddx_sum = (r.ddx.x + r.ddx.y) + r.ddx.z;
     float ddy_sum = (r.ddy.x + r.ddy.y) + r.ddy.z;
     const float dx = ndcx - n0x, dy = ndcy - n0y;
     const float interp_inv_w = (inv_w.x + dx * ddx_sum) + dy * ddy_sum;
-    const float interp_w = 1.0f / interp_inv_w;
+    const float interp_w = div_exact(1.0f, interp_inv_w);
     r.lambda.x = interp_w * ((inv_w.x + dx * r.ddx.x) + dy * r.ddy.x);
     r.lambda.y = interp_w * ((0.0f + dx * r.ddx.y) + dy * r.ddy.y);
     r.lambda.z = interp_w * ((0.0f + dx * r.ddx.z) + dy * r.ddy.z);
-    const float sx = 2.0f / winw, sy = 2.0f / winh;
+    const float sx = div_exact(2.0f, winw), sy = div_exact(2.0f, winh);
     r.ddx = r.ddx * sx;
     r.ddy = r.ddy * sy;
     ddx_sum *= sx;
     ddy_sum *= sy;
     r.ddy = r.ddy * -1.0f;
     ddy_sum *= -1.0f;
-    const float iwx = 1.0f / (interp_inv_w + ddx_sum), iwy = 1.0f / (interp_inv_w + ddy_sum);
+    const float iwx = div_exact(1.0f, interp_inv_w + ddx_sum), iwy = div_exact(1.0f, interp_inv_w + ddy_sum);
     r.ddx = ((r.lambda * interp_inv_w + r.ddx) * iwx) - r.lambda;
     r.ddy = ((r.lambda * interp_inv_w + r.ddy) * iwy) - r.lambda;
     return r;
