@@ -41,7 +41,7 @@ print("done, mismatching frames:", bad)
 # second part: instanced fields (prepared meshlets, simplified LOD chains, alpha-masked draws) from random cameras
 from renderer_amd import synth
 bad = 0
-for seed in range(200, 230):
+for seed in (range(200, 230) if os.environ.get("SWEEP_PART", "all") in ("all", "fields") else ()):
     rng = np.random.default_rng(seed)
     w, h = int(rng.integers(64, 900)), int(rng.integers(64, 600))
     subdiv = int(rng.integers(1, 4))
@@ -69,3 +69,36 @@ for seed in range(200, 230):
     if seed % 10 == 0:
         print("field seed", seed, "ok so far, bad =", bad, flush=True)
 print("fields done, mismatching frames:", bad)
+
+# third part: sort-last partitions of random scenes, composited with a 64-bit minimum on the host, against the
+# unpartitioned frame of the same renderer (bit for bit)
+bad = 0
+for seed in (range(300, 330) if os.environ.get("SWEEP_PART", "all") in ("all", "partitions") else ()):
+    rng = np.random.default_rng(seed)
+    w, h = int(rng.integers(32, 700)), int(rng.integers(32, 500))
+    if seed % 2:
+        sc = soup(rng, int(rng.integers(100, 1200)), bool(rng.integers(0, 2)))
+    else:
+        sc = synth.make_field(int(rng.integers(20, 200)), int(rng.integers(1, 4)), lods=1, alpha_fraction=float(rng.choice([0.0, 0.5])),
+                              with_env=False, seed=seed, prepared=True)
+    conf = RendererConfig(cull_enabled=bool(rng.integers(0, 2)))
+    g = Renderer(w, h, conf); g.set_scene(sc)
+    for _ in range(2):
+        g.render_visbuffer()
+    full = g.read_visbuffer_u64().copy()
+    parts = int(rng.integers(2, 8))
+    total = int(sc.meshlet_visibility_count)
+    cuts = sorted(set([0, total] + [int(c) for c in rng.integers(0, total + 1, parts - 1)]))
+    acc = np.full_like(full, np.uint64(0x7FFFFFFFFFFFFFFF))
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        p = Renderer(w, h, conf); p.set_scene(sc); p.set_partition(lo, hi)
+        for _ in range(2):
+            p.render_visbuffer()
+        acc = np.minimum(acc, p.read_visbuffer_u64())
+        p.close()
+    d = int((acc != full).sum())
+    if d:
+        bad += 1
+        print("MISMATCH partitions seed", seed, w, h, cuts, "keys", d, flush=True)
+    g.close()
+print("partitions done, mismatching scenes:", bad)
