@@ -102,3 +102,26 @@ for seed in (range(300, 330) if os.environ.get("SWEEP_PART", "all") in ("all", "
         print("MISMATCH partitions seed", seed, w, h, cuts, "keys", d, flush=True)
     g.close()
 print("partitions done, mismatching scenes:", bad)
+
+# fourth part: block-compressed textures of random shapes, GPU decode against the CPU decode
+if os.environ.get("SWEEP_PART", "all") in ("all", "bc"):
+    import ctypes as C
+    from renderer_amd import dds
+    from renderer_amd.scene import BlockImage
+    bad = 0
+    for seed in range(400, 600):
+        rng = np.random.default_rng(seed)
+        fmt = int(rng.integers(3, 7))  # RDR_FORMAT_BC1 .. BC4
+        w, h = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+        mips = int(rng.integers(1, int(np.log2(max(w, h))) + 2))
+        img = BlockImage(np.zeros(0, np.uint8), w, h, mips, fmt)
+        img.data = rng.integers(0, 256, sum(img.level_bytes(l) for l in range(mips)), dtype=np.uint8)
+        got = dds.decode(img).mips
+        dims = [(max(1, h >> l), max(1, w >> l)) for l in range(mips)]
+        want = np.zeros(sum(a * b for a, b in dims) * 4, np.uint8)
+        assert oracle.lib().orc_decode_bc(fmt, w, h, mips, img.data.ctypes.data_as(C.c_void_p), want.ctypes.data_as(C.c_void_p)) == 0
+        flat = np.concatenate([m.reshape(-1) for m in got])
+        if not np.array_equal(flat, want):
+            bad += 1
+            print("MISMATCH bc seed", seed, fmt, w, h, mips, flush=True)
+    print("bc done, mismatching images:", bad)
