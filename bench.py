@@ -7,14 +7,19 @@
 A step is one frame with the scene already resident in HBM.  The workload is the instanced
 icosphere field at 3840x2160 ("Field-S": 1 250 instances x 20 480 triangles = 25.6 M triangles
 per GPU), the stand-in for the Sponza / Bistro configurations whose assets do not ship with the
-reference.  With N > 1 each rank (one process per GPU, launched by torch.distributed.run) renders
-its share of an N-times larger field (weak scaling), the full-frame visibility buffers are
-composited with a 64-bit MIN all-reduce over RCCL, every rank shades H/N rows and the RGBA8 rows
-are all-gathered.  Rank 0 prints one JSON line.
+reference.  With N > 1 there is one process per GPU: started by torch.distributed.run, or, when
+WORLD_SIZE is not set, by this script itself, which then spawns its N ranks as fresh child
+processes before anything touches a GPU.  Every rank holds the whole scene and rasterises its
+contiguous share of the meshlet instances; the full-frame visibility buffers are composited with a
+64-bit MIN (reduce-scatter by row strips over RCCL), every rank shades H/N rows and the RGBA8 rows
+are all-gathered.  ``--scaling strong`` (the default) renders the same field at every N, ``weak``
+an N-times larger one.  Rank 0 prints one JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -124,6 +129,37 @@ def secondary_series(W, H, frames, instances, subdivisions):
     return out
 
 
+def spawn_ranks(n):
+    """Start the N ranks of a multi-GPU run as fresh child processes of this (GPU-free) parent:
+    same command line, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment.  Rank 0's
+    stdout (the JSON line) is this process's stdout; the exit code is non-zero if any rank's is."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if rank == 0 else sys.stderr))
+    codes = []
+    failed_at = None
+    while len(codes) < n:  # a rank that dies leaves the others waiting in a collective: end them too
+        for p in procs:
+            if p.poll() is not None and p.returncode != 0 and failed_at is None:
+                failed_at = time.time()
+        if all(p.poll() is not None for p in procs):
+            break
+        if failed_at is not None and time.time() - failed_at > 20:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.2)
+    codes = [p.wait() for p in procs]
+    return next((c for c in codes if c != 0), 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,7 +167,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--instances", type=int, default=1250, help="instances per GPU")
+    ap.add_argument("--instances", type=int, default=1250, help="instances of the field (per GPU with --scaling weak)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1: strong = the same scene at every N (the fixed-scene configurations), weak = N times the instances")
     ap.add_argument("--subdivisions", type=int, default=5)
     ap.add_argument("--cpu-frames", type=int, default=40, help="CPU-baseline frames, about 10 s of CPU work (0 = skip)")
     ap.add_argument("--secondary-frames", type=int, default=50,
@@ -146,6 +184,10 @@ def main():
     ap.add_argument("--force-collectives", action="store_true",
                     help="run the composite / gather collectives even with one rank (rehearsal)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher and never touches a GPU
+        raise SystemExit(spawn_ranks(args.gpus))
 
     # stdout carries exactly one JSON line: native libraries write to file descriptor 1 on their own (RCCL's
     # version banner, gloo's connection messages), so everything but that line is sent to stderr
@@ -182,7 +224,8 @@ def main():
 
     W, H = args.width, args.height
     # the sphere goes through the library's mesh preparation, as every mesh of the reference goes through append_mesh
-    scene = synth.make_field(args.instances * world, args.subdivisions, lods=1, with_env=True, prepared=True)
+    total_instances = args.instances * world if args.scaling == "weak" else args.instances
+    scene = synth.make_field(total_instances, args.subdivisions, lods=1, with_env=True, prepared=True)
     tris_per_frame = scene.triangle_count()
     # occlusion culling (cull_enabled) never changes the image; on this scene nothing hides behind anything, so the
     # second phase and the depth pyramid would only cost time (series "occlusion culling on" below)
@@ -260,16 +303,17 @@ def main():
             "ms_per_step": ms,
             "frames_per_s": fps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32+u64",
             "data": "synthetic",
             "config": {
-                "workload": f"field: {args.instances} instances/GPU x icosphere-{args.subdivisions} "
+                "workload": f"field: {total_instances} instances x icosphere-{args.subdivisions} "
                             f"({tris_per_frame / 1e6:.1f} Mtri submitted per frame, meshlets from the library's mesh preparation), "
                             f"{W}x{H}, lod off, occlusion culling off; "
                             "stand-in for the Sponza/Bistro 4K configs (assets not shipped)",
-                "instances": args.instances * world, "width": W, "height": H,
+                "instances": total_instances, "width": W, "height": H,
+                "ranks": dist.get_world_size() if multi else 1, "backend": (dist.get_backend() if multi else None),
                 "parallelism": "single GPU" if frame is None else
                                f"sort-last x{world}, u64-min {frame.composite.replace('_', '-')} + row-split shade + RGBA8 all-gather, "
                                f"{len(frame.slots)} frames in flight" + ("" if args.backend == "nccl" else " [gloo rehearsal]"),
