@@ -175,6 +175,17 @@ typedef struct rdr_image_desc {
 int rdr_decode_bc(int device, uint32_t format, uint32_t width, uint32_t height, uint32_t mip_count, const void* blocks,
                   size_t block_bytes, void* out_rgba8);
 
+/* rdr_decode_bc for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments
+ * and bit-identical output; the two staging buffers rdr_decode_bc allocates per call are replaced by
+ * a fixed array inside the library's code object (7.5 MiB per GPU, held until the process ends), and
+ * the call makes no hipMalloc / hipFree.  Limit: the chain's blocks must fit 1.5 MiB and its decoded
+ * levels (each padded to 16 bytes) 6 MiB, i.e. up to a full 1024 x 1024 mip chain in any of the four
+ * formats; a larger chain is refused with an error and nothing is written.  All calls on one GPU
+ * share the array: calls that overlap on one GPU race, the caller serialises them. */
+int rdr_decode_bc_noalloc(int device, uint32_t format, uint32_t width, uint32_t height, uint32_t mip_count,
+                          const void* blocks, size_t block_bytes, void* out_rgba8);
+
 /* Cubemap: mip-major; within a mip the six faces in Vulkan layer order
  * +X,-X,+Y,-Y,+Z,-Z; level i is max(1,size>>i) square. */
 typedef struct rdr_cubemap_desc {

@@ -9,7 +9,17 @@
 // ((7 - i)a + ib + 3) / 7 or ((5 - i)a + ib + 2) / 5 for the single-channel ramp.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "rdr_internal.h"
+
+// Staging memory of rdr_decode_bc_noalloc: the blocks of a mip chain in the first part, the decoded
+// texels in the second.  It lives in the code object, so every GPU the library runs on holds its
+// own copy, at its own address, until the process ends.  In host code this name is only a handle
+// for hipGetSymbolAddress: device code and copies go through the per-device address kept below.
+constexpr size_t kBcScratchBlocks = (size_t)3 << 19; // 1.5 MiB: blocks of a full 1024 x 1024 chain at 16 bytes per block
+constexpr size_t kBcScratchTexels = (size_t)6 << 20; // 6 MiB: its decoded RGBA8 levels, each padded to 16 bytes
+static __device__ __align__(256) uint8_t scratch[kBcScratchBlocks + kBcScratchTexels];
 
 namespace {
 
@@ -140,6 +150,67 @@ int rdr_launch_decode_bc(uint32_t format, uint32_t width, uint32_t height, const
     const uint32_t n = ((width + 3u) / 4u) * ((height + 3u) / 4u);
     hipLaunchKernelGGL(k_decode_bc, dim3((n + 255u) / 256u), dim3(256), 0, stream, format, width, height, blocks, out);
     RDR_HIP(hipGetLastError());
+    return 0;
+}
+
+namespace {
+// Address of `scratch` on each device, looked up once per device with that device current.
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+uint8_t* g_scratch_ptr[kMaxDevices] = {};
+
+int scratch_on_device(int device, uint8_t** out) {
+    RDR_CHECK(device >= 0 && device < kMaxDevices, "decode_bc_noalloc: device index out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        RDR_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        RDR_CHECK(p != nullptr, "decode_bc_noalloc: the staging array has no device address");
+        g_scratch_ptr[device] = static_cast<uint8_t*>(p);
+    }
+    *out = g_scratch_ptr[device];
+    return 0;
+}
+} // namespace
+
+// The variant of rdr_decode_bc for callers that must not allocate: same arguments, same result, its
+// two staging buffers replaced by the file-scope array above.  Calls no hipMalloc / hipFree.
+extern "C" int rdr_decode_bc_noalloc(int device, uint32_t format, uint32_t width, uint32_t height, uint32_t mip_count,
+                                     const void* blocks, size_t block_bytes, void* out_rgba8) {
+    RDR_CHECK(format >= RDR_FORMAT_BC1 && format <= RDR_FORMAT_BC4, "decode_bc_noalloc: format must be RDR_FORMAT_BC1 .. RDR_FORMAT_BC4");
+    RDR_CHECK(blocks && out_rgba8, "decode_bc_noalloc: null pointer");
+    RDR_CHECK(width && height && mip_count >= 1 && mip_count <= 17, "decode_bc_noalloc: dimensions / mip count invalid");
+    size_t need = 0, padded = 0;
+    size_t at[17]; // every decoded level starts on a 16-byte boundary of its own
+    for (uint32_t l = 0; l < mip_count; ++l) {
+        const uint32_t w = level_dim(width, l), h = level_dim(height, l);
+        need += rdr_bc_level_bytes(format, w, h);
+        at[l] = padded;
+        padded += ((size_t)w * h + 3) & ~(size_t)3;
+    }
+    RDR_CHECK(block_bytes >= need, "decode_bc_noalloc: block data shorter than the mip chain needs");
+    RDR_CHECK(need <= kBcScratchBlocks && padded * 4 <= kBcScratchTexels,
+              "decode_bc_noalloc: mip chain larger than the built-in staging memory (1.5 MiB of blocks, 6 MiB of "
+              "decoded texels: up to a full 1024 x 1024 chain); use rdr_decode_bc");
+    RDR_HIP(hipSetDevice(device));
+    uint8_t* base = nullptr;
+    if (scratch_on_device(device, &base)) return 1;
+    uint8_t* src = base;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(base + kBcScratchBlocks);
+    RDR_HIP(hipMemcpy(src, blocks, need, hipMemcpyHostToDevice));
+    size_t off = 0;
+    for (uint32_t l = 0; l < mip_count; ++l) {
+        const uint32_t w = level_dim(width, l), h = level_dim(height, l);
+        if (rdr_launch_decode_bc(format, w, h, src + off, dst + at[l], nullptr)) return 1;
+        off += rdr_bc_level_bytes(format, w, h);
+    }
+    RDR_HIP(hipStreamSynchronize(nullptr));
+    uint32_t* o = static_cast<uint32_t*>(out_rgba8);
+    for (uint32_t l = 0; l < mip_count; ++l) {
+        const size_t n = (size_t)level_dim(width, l) * level_dim(height, l);
+        RDR_HIP(hipMemcpy(o, dst + at[l], n * 4, hipMemcpyDeviceToHost));
+        o += n;
+    }
     return 0;
 }
 

@@ -20,6 +20,7 @@ ABI_SYMBOLS = [
     "rdr_set_stream", "rdr_sync", "rdr_read_visbuffer", "rdr_read_visbuffer_u64", "rdr_read_color",
     "rdr_get_stats", "rdr_build_ubo", "rdr_get_ubo", "rdr_destroy", "rdr_last_error",
     "rdr_bake_brdf_lut", "rdr_bake_env_map", "rdr_mesh_build", "rdr_mesh_result", "rdr_mesh_free", "rdr_decode_bc",
+    "rdr_decode_bc_noalloc",
 ]
 
 _LIB = None
@@ -70,6 +71,7 @@ def load_library():
     L.rdr_mesh_free.argtypes = [vp]
     L.rdr_mesh_free.restype = None
     L.rdr_decode_bc.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp]
+    L.rdr_decode_bc_noalloc.argtypes = L.rdr_decode_bc.argtypes
     _LIB = L
     return L
 
