@@ -301,6 +301,23 @@ int rdr_update_transforms(rdr_renderer* r, const float* mat4s, uint32_t count);
 int rdr_render(rdr_renderer* r, const float cam_pos[3], const float cam_dir[3],
                const float sun_dir[3]);
 
+/* Work a frame had to drop because a list filled up.  The reference cannot drop work (its lists are
+ * sized by the driver); here every list has a capacity fixed at rdr_set_scene, and a frame that
+ * exceeds one is reported, never silently wrong: the kernels leave these flags in pinned host
+ * memory, and the next rdr_render / rdr_render_visbuffer / rdr_shade on the renderer looks at
+ * them first (no synchronisation) and fails with a message if the last finished frame dropped work,
+ * as a Vulkan call of the reference's render() would fail through `?` (renderer.rs:862-1002);
+ * readbacks and rdr_get_stats fail the same way.  rdr_frame_status waits for the submitted work and
+ * returns the flags of the last frame in *flags (0 = complete) without raising an error. */
+#define RDR_FRAME_DEFERRED_OVERFLOW 1u /* clip / tile path: deferred triangle list */
+#define RDR_FRAME_SETUP_OVERFLOW 2u    /* tile path: screen-space records */
+#define RDR_FRAME_BIN_OVERFLOW 4u      /* tile path: per-tile bins */
+#define RDR_FRAME_MID_OVERFLOW 8u      /* mid-sized triangle queue */
+#define RDR_FRAME_FRAG_OVERFLOW 16u    /* alpha-tested fragment queue */
+#define RDR_FRAME_LIST_OVERFLOW 32u    /* cull command / visible meshlet lists */
+#define RDR_FRAME_SHADOW_STACK 64u     /* a shadow ray's traversal stack overflowed without a hit: its pixel may be lit wrongly */
+int rdr_frame_status(rdr_renderer* r, uint32_t* flags);
+
 /* The two halves of rdr_render, for sort-last rendering: geometry into the
  * 64-bit visibility buffer, (composite by the caller), then shading. */
 int rdr_render_visbuffer(rdr_renderer* r, const float cam_pos[3], const float cam_dir[3],
@@ -319,7 +336,9 @@ int rdr_set_shade_rows(rdr_renderer* r, uint32_t row_lo, uint32_t row_hi);
 void* rdr_visbuffer_device_ptr(rdr_renderer* r);
 void* rdr_color_device_ptr(rdr_renderer* r);
 
-/* Run on the caller's HIP stream (hipStream_t) instead of the library's own. */
+/* Run on the caller's HIP stream (hipStream_t) instead of the library's own.  NULL goes back to the
+ * library's own (non-blocking) stream; to select HIP's null stream pass hipStreamLegacy, HIP's handle
+ * for it ((hipStream_t)1), which like hipStreamPerThread is handed to the runtime unchanged. */
 int rdr_set_stream(rdr_renderer* r, void* hip_stream);
 int rdr_sync(rdr_renderer* r);
 

@@ -429,7 +429,10 @@ static void make_alpha_test(const rdr_scene_desc* s, const rdr_mesh_draw* d, alp
     const rdr_material* mat = &s->materials[d->material_index];
     at->factor_a = mat->base_color_factor[3];
     at->cutoff = mat->emissive_factor_alpha_cutoff[3];
-    if (mat->albedo_texture != RDR_NO_TEXTURE && mat->albedo_texture < s->image_count) {
+    if (mat->albedo_texture != RDR_NO_TEXTURE && mat->albedo_texture < s->image_count &&
+        s->images[mat->albedo_texture].data == NULL) {
+        at->factor_a = 0.0f; /* an image without data samples as zero: alpha = 0 * factor */
+    } else if (mat->albedo_texture != RDR_NO_TEXTURE && mat->albedo_texture < s->image_count) {
         at->has_tex = 1;
         at->tex = &s->images[mat->albedo_texture];
         at->uv_set = mat->albedo_texture_uv == 0 ? 0 : 1;

@@ -128,6 +128,12 @@ struct rdr_renderer {
     uint32_t lane_max_pixels = kLaneMaxPixels, mid_max_pixels = kMidMaxPixels;
     uint32_t masked_meshlets = 0; // LOD0 meshlet instances of alpha-masked draws
     rdr_stats stats{};
+    // frame status words the kernels write (pinned host memory, see FrameView::host_status)
+    volatile uint32_t* status_host = nullptr;
+    uint32_t* status_dev = nullptr;
+    uint32_t frame_seq = 0;
+    uint32_t seen_status[2] = {0, 0};
+    uint32_t debug_deferred_capacity = 0xFFFFFFFFu; // test hook: smaller deferred list
 };
 
 namespace {
@@ -357,6 +363,9 @@ FrameView make_frame_view(rdr_renderer* r) {
     fv.shadow = r->shadow.ptr;
     fv.pixel_list = r->pixel_list.ptr;
     fv.lds_stack_limit = r->lds_stack_limit;
+    fv.host_status = r->status_dev;
+    fv.frame_seq = r->frame_seq & 0xFFFFFFu;
+    fv.deferred_capacity = std::min(fv.deferred_capacity, r->debug_deferred_capacity);
     fv.setup = r->setup.ptr;
     fv.setup_mask = r->setup_mask.ptr;
     fv.tile_count = r->tile_count.ptr;
@@ -419,10 +428,46 @@ FrameView make_frame_view(rdr_renderer* r) {
 int fetch_counters(rdr_renderer* r, FrameCounters* out) {
     RDR_HIP(hipStreamSynchronize(r->stream));
     RDR_HIP(hipMemcpy(out, r->counters.ptr, sizeof(FrameCounters), hipMemcpyDeviceToHost));
+    r->seen_status[0] = r->status_host[0]; // this call reports the frame itself
+    r->seen_status[1] = r->status_host[1];
     RDR_CHECK(out->deferred_overflow == 0 && out->setup_overflow == 0 && out->bin_overflow == 0 && out->mid_overflow == 0 && out->frag_overflow == 0,
               "frame: a tile-path list (deferred triangles, setup records or bins) overflowed; triangles were dropped");
+    RDR_CHECK(out->deep_overflow == 0, "frame: a shadow ray's traversal stack overflowed; its pixel may be lit wrongly");
     RDR_CHECK(out->cmd_count <= r->commands.count && (uint64_t)out->vis_count + out->vis_mask_count <= r->visible.count,
               "frame: a work list overflowed");
+    return 0;
+}
+
+std::string status_message(uint32_t flags) {
+    std::string m;
+    auto add = [&](uint32_t bit, const char* what) {
+        if (flags & bit) m += (m.empty() ? "" : ", ") + std::string(what);
+    };
+    add(RDR_FRAME_DEFERRED_OVERFLOW, "deferred triangle list");
+    add(RDR_FRAME_SETUP_OVERFLOW, "tile set-up records");
+    add(RDR_FRAME_BIN_OVERFLOW, "tile bins");
+    add(RDR_FRAME_MID_OVERFLOW, "mid-sized triangle queue");
+    add(RDR_FRAME_FRAG_OVERFLOW, "alpha-tested fragment queue");
+    add(RDR_FRAME_LIST_OVERFLOW, "cull command / visible meshlet list");
+    add(RDR_FRAME_SHADOW_STACK, "shadow-ray traversal stack");
+    return m;
+}
+
+// Looks at the status words the kernels of earlier frames left in host memory (no synchronisation: a frame
+// still in flight is seen by a later call) and fails once for every finished frame that dropped work.
+int check_finished_frames(rdr_renderer* r, const char* who) {
+    uint32_t bad = 0;
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t w = r->status_host[h];
+        if (w != r->seen_status[h]) {
+            r->seen_status[h] = w;
+            bad |= w & 0xFFu;
+        }
+    }
+    if (bad) {
+        rdr_set_error(std::string(who) + ": an earlier frame dropped work (" + status_message(bad) + " overflowed); its image is incomplete");
+        return 1;
+    }
     return 0;
 }
 
@@ -479,6 +524,17 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
         RDR_HIP(hipMemset(r->tile_count.ptr, 0, n_tiles * 4));
     }
     RDR_HIP(hipMemset(r->counters.ptr, 0, sizeof(FrameCounters)));
+    {
+        void* host = nullptr;
+        void* dev = nullptr;
+        RDR_HIP(hipHostMalloc(&host, 64, hipHostMallocMapped));
+        std::memset(host, 0, 64);
+        r->status_host = static_cast<volatile uint32_t*>(host);
+        RDR_HIP(hipHostGetDevicePointer(&dev, host, 0));
+        r->status_dev = static_cast<uint32_t*>(dev);
+    }
+    if (const char* e = std::getenv("RDR_DEBUG_DEFERRED_CAPACITY")) // test hook: force the deferred list to overflow
+        r->debug_deferred_capacity = (uint32_t)std::max(1, std::atoi(e));
     float lut[256];
     for (int i = 0; i < 256; ++i) {
         const float c = (float)i / 255.0f;
@@ -495,12 +551,15 @@ void rdr_destroy(rdr_renderer* r) {
     (void)hipStreamSynchronize(r->stream);
     for (auto& e : r->ring) (void)hipEventDestroy(e);
     if (r->own_stream) (void)hipStreamDestroy(r->own_stream);
+    if (r->status_host) (void)hipHostFree(const_cast<uint32_t*>(r->status_host));
     delete r;
 }
 
 int rdr_set_stream(rdr_renderer* r, void* hip_stream) {
     RDR_CHECK(r, "rdr_set_stream: renderer is null");
     RDR_HIP(hipStreamSynchronize(r->stream));
+    // null selects the library's own stream; hipStreamLegacy / hipStreamPerThread (HIP's special handles) select
+    // the null stream and the per-thread stream and are passed through as they are
     r->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : r->own_stream;
     return 0;
 }
@@ -571,20 +630,30 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
         r->masked_meshlets = (uint32_t)masked_total;
     }
     if (r->commands.alloc(cmd_cap) || r->visible.alloc(vis_cap)) return 1;
+    // The mid and alpha-fragment queues are cut into 32 segments and a workgroup of the producing kernel always
+    // uses segment blockIdx % 32: a segment must hold everything the workgroups mapped to it can queue, i.e.
+    // (meshlets per workgroup) x (workgroups per segment) x 124 triangles.
+    auto segment_worst = [](uint64_t meshlets, uint32_t resident) -> uint64_t {
+        const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>(meshlets, std::max(1u, resident)));
+        return ((meshlets + grid - 1) / grid) * ((grid + 31) / 32) * 124;
+    };
     {
         // tile path: deferred clip-space triangles, their screen-space records (clipping can fan one
         // triangle into several) and the per-tile bins
         // at most every LOD-0 triangle, capped at 4 M per frame (about 1.6 GB of lists at the cap; a frame that
         // needs more reports an overflow error instead of dropping triangles silently)
         const size_t n_def = (size_t)std::min<uint64_t>(std::max<uint64_t>(tri_total, 1u << 16), 1u << 22);
+        // mid queue: k_raster's opaque mid-sized triangles plus the alpha-tested ones k_tile_setup passes on from
+        // the deferred list (its 1024 workgroups take deferred triangles a grid apart: n_def / 32 + 32 per segment)
+        const size_t n_mid = (size_t)std::min<uint64_t>(32 * (segment_worst(vis_cap, r->resident.raster) + n_def / 32 + 32), (uint64_t)2 << 22);
         if (r->deferred.alloc(n_def) || r->setup.alloc(n_def + n_def / 2) || r->setup_mask.alloc(n_def + n_def / 2) ||
-            r->mid.alloc(n_def) || r->mid_mask.alloc(n_def)) return 1;
+            r->mid.alloc(n_mid) || r->mid_mask.alloc(n_mid)) return 1;
         if (r->bin_entries.alloc(std::max<size_t>(n_def * 4, (size_t)1 << 22))) return 1;
         // jobs of the tile rasteriser: at most one partly filled job per tile plus the full ones
         if (r->tile_list.alloc(((size_t)r->tile_count.count + r->bin_entries.count / kTileJob + 1) * 4)) return 1; // x parts per tile
         // small alpha-tested triangles and their covered pixels (at most 16 each): every LOD-0 triangle of the
         // alpha-tested draws, capped like the lists above
-        const size_t n_frag = (size_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)r->masked_meshlets * 124, 1u << 12), 1u << 22);
+        const size_t n_frag = (size_t)std::min<uint64_t>(std::max<uint64_t>(32 * segment_worst(r->masked_meshlets, r->resident.raster_mask), 1u << 12), 1u << 22);
         if (r->frag_tri.alloc(n_frag) || r->frag_px.alloc(n_frag * 16)) return 1;
         // zeroed once: a consumer that meets a never-written entry (only possible after an overflow, which is
         // reported as an error) then reads a valid index
@@ -701,6 +770,8 @@ int rdr_render_visbuffer(rdr_renderer* r, const float cam_pos[3], const float ca
     RDR_CHECK(r && cam_pos && cam_dir && sun_dir, "rdr_render_visbuffer: null argument");
     RDR_CHECK(r->has_scene, "rdr_render_visbuffer: no scene set");
     RDR_HIP(hipSetDevice(r->device));
+    if (check_finished_frames(r, "rdr_render_visbuffer")) return 1;
+    r->frame_seq++;
     build_ubo(r->width, r->height, cam_pos, cam_dir, sun_dir, r->sv.draw_count, r->cfg.lod_enabled, r->cfg.cull_enabled, &r->ubo);
     const FrameView fv = make_frame_view(r);
     hipEvent_t* ev = nullptr;
@@ -721,6 +792,7 @@ int rdr_shade(rdr_renderer* r) {
     RDR_CHECK(r, "rdr_shade: renderer is null");
     RDR_CHECK(r->has_scene && r->frame_rendered, "rdr_shade: no visibility buffer rendered yet");
     RDR_HIP(hipSetDevice(r->device));
+    if (check_finished_frames(r, "rdr_shade")) return 1;
     FrameView fv = make_frame_view(r);
     fv.list_heads_zero = r->shaded ? 0u : 1u; // first shading pass over this visibility buffer
     hipEvent_t* ev = r->cfg.time_kernels ? r->ring.data() + (size_t)r->cur_slot * rdr_renderer::kEvents : nullptr;
@@ -733,6 +805,16 @@ int rdr_shade(rdr_renderer* r) {
 int rdr_render(rdr_renderer* r, const float cam_pos[3], const float cam_dir[3], const float sun_dir[3]) {
     if (rdr_render_visbuffer(r, cam_pos, cam_dir, sun_dir)) return 1;
     return rdr_shade(r);
+}
+
+int rdr_frame_status(rdr_renderer* r, uint32_t* flags) {
+    RDR_CHECK(r && flags, "rdr_frame_status: null argument");
+    RDR_HIP(hipSetDevice(r->device));
+    RDR_HIP(hipStreamSynchronize(r->stream));
+    r->seen_status[0] = r->status_host[0];
+    r->seen_status[1] = r->status_host[1];
+    *flags = (r->seen_status[0] | r->seen_status[1]) & 0xFFu;
+    return 0;
 }
 
 void* rdr_visbuffer_device_ptr(rdr_renderer* r) { return r ? r->vis.ptr : nullptr; }

@@ -338,7 +338,9 @@ RDR_DEV AlphaTest make_alpha_test(const SceneView& sv, const rdr_mesh_draw& d) {
         at.factor_a = mat->base_color_factor[3];
         at.cutoff = mat->emissive_factor_alpha_cutoff[3];
         const uint32_t tex = mat->albedo_texture;
-        if (tex != RDR_NO_TEXTURE && tex < sv.image_count) {
+        if (tex != RDR_NO_TEXTURE && tex < sv.image_count && sv.images[tex].mip_count == 0u) {
+            at.factor_a = 0.0f; // an image without data samples as zero (as in the shading pass): alpha = 0 * factor
+        } else if (tex != RDR_NO_TEXTURE && tex < sv.image_count) {
             at.has_tex = true;
             at.image = tex;
             at.uv_set = mat->albedo_texture_uv == 0u ? 0u : 1u;
@@ -1336,6 +1338,20 @@ __global__ __launch_bounds__((kTilePart / B) * (kTilePart / B)) void k_tile_rast
     static_assert(kTileJob <= kTileBatch, "a job is staged in one batch");
     uint32_t frags = 0;
     const uint32_t n_listed = min(fv.counters->tile_nonempty, fv.tile_list_capacity);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // last kernel of the geometry half: every producer of the lists has finished, so the overflow
+        // counters are final; leave the frame's status where the host sees it without a synchronisation
+        const FrameCounters* c = fv.counters;
+        uint32_t flags = 0;
+        flags |= c->deferred_overflow ? RDR_FRAME_DEFERRED_OVERFLOW : 0u;
+        flags |= c->setup_overflow ? RDR_FRAME_SETUP_OVERFLOW : 0u;
+        flags |= c->bin_overflow ? RDR_FRAME_BIN_OVERFLOW : 0u;
+        flags |= c->mid_overflow ? RDR_FRAME_MID_OVERFLOW : 0u;
+        flags |= c->frag_overflow ? RDR_FRAME_FRAG_OVERFLOW : 0u;
+        flags |= (c->cmd_count > fv.command_capacity || (unsigned long long)c->vis_count + c->vis_mask_count > fv.visible_capacity)
+                     ? RDR_FRAME_LIST_OVERFLOW : 0u;
+        __hip_atomic_store(&fv.host_status[0], (fv.frame_seq << 8) | flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     // Jobs are dealt out by index, a grid's width apart: a shared counter would cost an atomic that returns a
     // value per job, and those serialise on their address (10 000 jobs: 0.1 ms).
     for (uint32_t this_li = blockIdx.x; this_li < n_listed; this_li += gridDim.x) {

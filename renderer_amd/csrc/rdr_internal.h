@@ -116,7 +116,8 @@ struct FrameCounters {
     uint32_t vis_mask_count;  // alpha-masked meshlets, stored from the back of `visible`
     uint32_t tile_nonempty;   // jobs of the tile rasteriser this pass (length of tile_list)
     uint32_t mid_overflow;
-    uint32_t _pad0[3];
+    uint32_t deep_overflow;   // shadow rays whose deep (scratch) stack dropped entries without finding a hit
+    uint32_t _pad0[2];
     unsigned long long _pad1[16];
     // SetupTri records queued for k_mid_raster, per segment of the queue.  Every wave of k_raster
     // reserves its slots with an atomic that returns a value, and same-address atomics serialise
@@ -337,6 +338,11 @@ struct FrameView {
     uint32_t pyr_levels;
     uint32_t pyr_offset[16], pyr_w[16], pyr_h[16];
     uint32_t lds_stack_limit; // entries of the LDS traversal stack in use (<= 24; lowered only by tests)
+    // Frame status in pinned host memory: word 0 is written by the last kernel of the geometry half, word 1 by
+    // the last kernel of the shading half, each as frame_seq << 8 | RDR_FRAME_* flags, so that the host learns
+    // of dropped work without synchronising (it looks at the words when the next frame is submitted).
+    uint32_t* host_status;
+    uint32_t frame_seq;
     // Per-workgroup statistics: every workgroup stores its partial counts in its own
     // slot with plain stores (no contended atomics); the host sums the slots on request.
     uint32_t* stat_slots;

@@ -297,6 +297,9 @@ RDR_DEV vec3 shade_pixel(const SceneView& sv, const rdr_ubo& u, uint32_t draw_id
 // Pass 2: material evaluation, lighting, sRGB store of every covered pixel.
 __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv) {
     const uint32_t entry = blockIdx.x * 256u + threadIdx.x;
+    if (entry == 0u) // last kernel of the shading half that every frame runs: the frame's status for the host
+        __hip_atomic_store(&fv.host_status[1], (fv.frame_seq << 8) | (fv.counters->deep_overflow ? RDR_FRAME_SHADOW_STACK : 0u),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (entry >= fv.counters->pixel_count) return;
     const ListedPixel p = listed_pixel(sv, fv, entry);
     const vec3 c = shade_pixel(sv, fv.ubo, p.draw_id, p.meshlet, p.tri, p.uvx, p.uvy, fv.shadow[entry] != 0);

@@ -331,7 +331,9 @@ __global__ __launch_bounds__(256) void k_shadow_deep(SceneView sv, FrameView fv)
         const vec3 w_pos = pixel_world_position(sv, u, p.draw_id, p.meshlet, p.tri, p.uvx, p.uvy);
         const vec3 L = normalize3(mk3(u.sun_direction[0], u.sun_direction[1], u.sun_direction[2]));
         DeepStack st;
-        fv.shadow[entry] = shadow_any_hit(sv, p.draw_id, w_pos, L, 1e-2f, 1000.0f, st) ? 1 : 0;
+        const bool h = shadow_any_hit(sv, p.draw_id, w_pos, L, 1e-2f, 1000.0f, st);
+        if (!h && st.overflow) atomicAdd(&fv.counters->deep_overflow, 1u); // a miss that dropped entries proves nothing: reported
+        fv.shadow[entry] = h ? 1 : 0;
     }
 }
 

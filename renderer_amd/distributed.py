@@ -95,8 +95,21 @@ class SortLastFrame:
         self.composite = composite
         renderer.set_partition(*instance_range(n_instances, rank, world))
         renderer.set_shade_rows(*row_range(height, rank, world))
+        self._stream_handle = None
+
+    def _follow_current_stream(self):
+        """The collectives run on torch's current stream: the renderer's kernels must be ordered on
+        the same one (its own private stream would race with them).  Handle 0 is HIP's null stream,
+        which the library is told by its explicit handle (hipStreamLegacy = 1)."""
+        if not getattr(self.vis, "is_cuda", False) or not hasattr(self.r, "set_stream"):
+            return
+        handle = torch.cuda.current_stream().cuda_stream or 1
+        if handle != self._stream_handle:
+            self.r.set_stream(handle)
+            self._stream_handle = handle
 
     def step(self, camera=None, sun=None):
+        self._follow_current_stream()
         self.r.render_visbuffer(camera, sun)
         if self.composite == "reduce_scatter":
             try:
@@ -125,7 +138,6 @@ class SortLastPipeline:
         for _ in range(max(1, depth)):
             r = make_renderer()
             stream = torch.cuda.Stream()
-            r.set_stream(stream.cuda_stream)
             vis = torch.as_tensor(r.visbuffer_device_array(), device="cuda")
             color = torch.as_tensor(r.color_device_array(), device="cuda")
             self.slots.append((SortLastFrame(r, n_instances, height, rank, world, vis, color, composite), stream))

@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "rdr_set_stream", "rdr_sync", "rdr_read_visbuffer", "rdr_read_visbuffer_u64", "rdr_read_color",
     "rdr_get_stats", "rdr_build_ubo", "rdr_get_ubo", "rdr_destroy", "rdr_last_error",
     "rdr_bake_brdf_lut", "rdr_bake_env_map", "rdr_mesh_build", "rdr_mesh_result", "rdr_mesh_free", "rdr_decode_bc",
-    "rdr_decode_bc_noalloc",
+    "rdr_decode_bc_noalloc", "rdr_frame_status",
 ]
 
 _LIB = None
@@ -61,6 +61,7 @@ def load_library():
     L.rdr_read_visbuffer_u64.argtypes = [vp, vp]
     L.rdr_read_color.argtypes = [vp, vp]
     L.rdr_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
+    L.rdr_frame_status.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.rdr_build_ubo.argtypes = [C.c_uint32, C.c_uint32, f3, f3, f3, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(abi.Ubo)]
     L.rdr_get_ubo.argtypes = [vp, C.POINTER(abi.Ubo)]
     L.rdr_destroy.argtypes = [vp]
@@ -188,6 +189,12 @@ class Renderer:
         out = np.empty((self.height, self.width, 4), np.uint8)
         self._check(self._L.rdr_read_color(self._h, out.ctypes.data))
         return out
+
+    def frame_status(self):
+        """Waits for the submitted frames; ``abi.FRAME_*`` flags of the last one (0 = nothing was dropped)."""
+        flags = C.c_uint32(0)
+        self._check(self._L.rdr_frame_status(self._h, C.byref(flags)))
+        return int(flags.value)
 
     def stats(self):
         st = abi.Stats()

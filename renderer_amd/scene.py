@@ -224,6 +224,8 @@ class Scene:
             return a.ctypes.data_as(C.c_void_p) if a.size else None
 
         def image_desc(img):
+            if img is None:  # an image the loader skipped (embedded / missing file): data == NULL samples as zero
+                return abi.ImageDesc(None, 0, 0, 0, 0)
             if isinstance(img, BlockImage):
                 blob = np.ascontiguousarray(img.data, np.uint8).reshape(-1)
                 need = sum(img.level_bytes(l) for l in range(img.mip_count))
