@@ -12,6 +12,9 @@
 #include <cstring>
 #include <limits>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "rdr_internal.h"
 
 namespace {
@@ -277,6 +280,126 @@ void affine_inverse(const float* m, float* out12) {
     out12[11] = (float)(-(i20 * tx + i21 * ty + i22 * tz));
 }
 
+// Is the mesh's LOD-0 triangle list the closed, consistently wound boundary of a convex body?
+// Vertices are welded by position first (uv seams duplicate them).  Closed and consistently wound: every
+// directed edge occurs once and so does its reverse.  Convex: every vertex lies on or behind every face
+// plane, up to `tol`; what is tolerated is returned as the protrusion, which the ray margin then covers.
+// Quadratic in the mesh size, so only meshes up to a work limit are examined (larger ones count as not
+// convex), and results are remembered per mesh content for the life of the process.
+struct Convexity {
+    int8_t sign = 0;
+    float protrusion = 0.0f;
+};
+
+uint64_t fnv1a(const void* data, size_t n, uint64_t h) {
+    const uint8_t* p = static_cast<const uint8_t*>(data);
+    for (size_t i = 0; i < n; ++i) h = (h ^ p[i]) * 0x100000001B3ull;
+    return h;
+}
+
+Convexity analyse_convexity(const rdr_scene_desc& s, uint32_t mi) {
+    const rdr_mesh& mesh = s.meshes[mi];
+    const uint32_t nidx = mesh_index_count(s, mi), ntri = nidx / 3;
+    Convexity none;
+    if (ntri < 4) return none;
+    // weld by position
+    std::vector<uint32_t> weld(mesh.vertex_count);
+    std::vector<double> px, py, pz;
+    {
+        struct Key {
+            uint32_t x, y, z;
+            bool operator==(const Key& o) const { return x == o.x && y == o.y && z == o.z; }
+        };
+        struct Hash {
+            size_t operator()(const Key& k) const { return (size_t)(((uint64_t)k.x * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)k.y << 21) ^ ((uint64_t)k.z * 0xC2B2AE3D27D4EB4Full)); }
+        };
+        std::unordered_map<Key, uint32_t, Hash> ids;
+        ids.reserve(mesh.vertex_count * 2);
+        for (uint32_t v = 0; v < mesh.vertex_count; ++v) {
+            const float* p = s.vertices[mesh.vertex_offset + v].p;
+            Key k;
+            float q[3] = {p[0] + 0.0f, p[1] + 0.0f, p[2] + 0.0f}; // -0 and +0 are the same place
+            std::memcpy(&k, q, 12);
+            auto it = ids.find(k);
+            if (it == ids.end()) {
+                it = ids.emplace(k, (uint32_t)px.size()).first;
+                px.push_back(p[0]); py.push_back(p[1]); pz.push_back(p[2]);
+            }
+            weld[v] = it->second;
+        }
+    }
+    const size_t nv = px.size();
+    if ((double)ntri * (double)nv > 1.0e9) return none;
+    std::vector<uint32_t> tri(3 * (size_t)ntri);
+    std::unordered_map<uint64_t, uint32_t> edges;
+    edges.reserve(3 * (size_t)ntri * 2);
+    for (uint32_t t = 0; t < ntri; ++t) {
+        uint32_t v[3];
+        for (int k = 0; k < 3; ++k) v[k] = tri[3 * (size_t)t + k] = weld[s.indices[mesh.index_offset + 3 * t + k]];
+        if (v[0] == v[1] || v[1] == v[2] || v[2] == v[0]) return none;
+        for (int k = 0; k < 3; ++k)
+            if (++edges[((uint64_t)v[k] << 32) | v[(k + 1) % 3]] > 1) return none;
+    }
+    for (const auto& e : edges) {
+        const auto r = edges.find((e.first << 32) | (e.first >> 32));
+        if (r == edges.end()) return none;
+    }
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (size_t v = 0; v < nv; ++v) {
+        lo[0] = std::min(lo[0], px[v]); hi[0] = std::max(hi[0], px[v]);
+        lo[1] = std::min(lo[1], py[v]); hi[1] = std::max(hi[1], py[v]);
+        lo[2] = std::min(lo[2], pz[v]); hi[2] = std::max(hi[2], pz[v]);
+    }
+    const double extent = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+    const double tol = 1e-5 * extent;
+    double above = 0.0, below = 0.0; // largest distance of a vertex in front of / behind a face plane
+    for (uint32_t t = 0; t < ntri; ++t) {
+        const uint32_t a = tri[3 * (size_t)t], b = tri[3 * (size_t)t + 1], c = tri[3 * (size_t)t + 2];
+        const double e1[3] = {px[b] - px[a], py[b] - py[a], pz[b] - pz[a]}, e2[3] = {px[c] - px[a], py[c] - py[a], pz[c] - pz[a]};
+        double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+        const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        if (!(len > 0.0)) return none;
+        n[0] /= len; n[1] /= len; n[2] /= len;
+        const double d0 = n[0] * px[a] + n[1] * py[a] + n[2] * pz[a];
+        double mx = -1e300, mn = 1e300;
+        for (size_t v = 0; v < nv; ++v) {
+            const double d = n[0] * px[v] + n[1] * py[v] + n[2] * pz[v];
+            mx = std::max(mx, d);
+            mn = std::min(mn, d);
+        }
+        above = std::max(above, mx - d0);
+        below = std::max(below, d0 - mn);
+        if (above > tol && below > tol) return none;
+    }
+    Convexity out;
+    if (above <= tol) { out.sign = 1; out.protrusion = (float)above; }
+    else { out.sign = -1; out.protrusion = (float)below; }
+    return out;
+}
+
+Convexity mesh_convexity(const rdr_scene_desc& s, uint32_t mi) {
+    static std::mutex mutex;
+    static std::unordered_map<uint64_t, std::pair<uint64_t, Convexity>> cache;
+    const rdr_mesh& mesh = s.meshes[mi];
+    const uint32_t nidx = mesh_index_count(s, mi);
+    uint64_t h1 = 0xCBF29CE484222325ull, h2 = 0x84222325CBF29CE4ull;
+    for (uint32_t v = 0; v < mesh.vertex_count; ++v) {
+        h1 = fnv1a(s.vertices[mesh.vertex_offset + v].p, 12, h1);
+        h2 = fnv1a(s.vertices[mesh.vertex_offset + v].p, 12, h2 * 31 + 7);
+    }
+    h1 = fnv1a(s.indices + mesh.index_offset, (size_t)nidx * 4, h1);
+    h2 = fnv1a(s.indices + mesh.index_offset, (size_t)nidx * 4, h2 * 31 + 7);
+    {
+        std::lock_guard<std::mutex> lock(mutex);
+        const auto it = cache.find(h1);
+        if (it != cache.end() && it->second.first == h2) return it->second.second;
+    }
+    const Convexity c = analyse_convexity(s, mi);
+    std::lock_guard<std::mutex> lock(mutex);
+    cache[h1] = {h2, c};
+    return c;
+}
+
 } // namespace
 
 void rdr_build_blas(const rdr_scene_desc& s, HostBvh& out) {
@@ -286,6 +409,8 @@ void rdr_build_blas(const rdr_scene_desc& s, HostBvh& out) {
     out.blas_tris.clear();
     out.mesh_root.assign(s.mesh_count, 0);
     out.mesh_tri_base.assign(s.mesh_count, 0);
+    out.mesh_convex_sign.assign(s.mesh_count, 0);
+    out.mesh_protrusion.assign(s.mesh_count, 0.0f);
     std::vector<BvhNode> nodes;
     std::vector<Item> items;
     for (uint32_t mi = 0; mi < s.mesh_count; ++mi) {
@@ -309,6 +434,11 @@ void rdr_build_blas(const rdr_scene_desc& s, HostBvh& out) {
             it.index = t;
         }
         build(nodes, items);
+        {
+            const Convexity cx = mesh_convexity(s, mi);
+            out.mesh_convex_sign[mi] = cx.sign;
+            out.mesh_protrusion[mi] = cx.protrusion;
+        }
         out.mesh_root[mi] = (uint32_t)out.blas_pairs.size();
         out.mesh_tri_base[mi] = (uint32_t)(out.blas_tris.size() / 9);
         out.mesh_bounds[mi] = nodes[0];
@@ -334,7 +464,8 @@ void rdr_build_tlas(const rdr_scene_desc& s, const float* transforms, HostBvh& i
         affine_inverse(m, inst.inv);
         inst.blas_root = io.mesh_root[d.mesh_index];
         inst.tri_base = io.mesh_tri_base[d.mesh_index];
-        inst._pad[0] = inst._pad[1] = 0;
+        inst._pad = 0;
+        inst.convex_cos = 0.0f;
         const BvhNode& root = io.mesh_bounds[d.mesh_index];
         Item& it = items[di];
         it.box.reset();
@@ -358,6 +489,21 @@ void rdr_build_tlas(const rdr_scene_desc& s, const float* transforms, HostBvh& i
             it.box.grow(far_away);
         }
         for (int k = 0; k < 3; ++k) it.c[k] = 0.5f * (it.box.lo[k] + it.box.hi[k]);
+        if (io.mesh_convex_sign[d.mesh_index] != 0 && root.lo[0] <= root.hi[0]) {
+            // A ray that leaves a face at cosine c to its outward normal is c * tmin above the face plane when the
+            // triangle tests start to count (tmin = 0.01).  That clearance must exceed what rounding can move: the
+            // origin (interpolated world position) and the object-space triangle tests are good to a few units in
+            // the last place of the largest world coordinate M involved (64 of them are allowed for), plus the
+            // mesh's own deviation from exact convexity, stretched by the model matrix.
+            const double det = (double)m[0] * ((double)m[5] * m[10] - (double)m[6] * m[9]) - (double)m[4] * ((double)m[1] * m[10] - (double)m[2] * m[9]) +
+                               (double)m[8] * ((double)m[1] * m[6] - (double)m[2] * m[5]);
+            double scale = 0.0, M = 0.0;
+            for (int c = 0; c < 3; ++c) scale = std::max(scale, std::sqrt((double)m[4 * c] * m[4 * c] + (double)m[4 * c + 1] * m[4 * c + 1] + (double)m[4 * c + 2] * m[4 * c + 2]));
+            for (int k = 0; k < 3; ++k) M = std::max(M, std::max(std::fabs((double)it.box.lo[k]), std::fabs((double)it.box.hi[k])));
+            const double cos_min = std::max(0.01, (16.0 * 1.1920929e-7 * M + 4.0 * io.mesh_protrusion[d.mesh_index] * scale) / 0.01);
+            if (det != 0.0 && std::isfinite(det) && cos_min < 0.95)
+                inst.convex_cos = (float)(cos_min * (double)io.mesh_convex_sign[d.mesh_index] * (det > 0.0 ? 1.0 : -1.0));
+        }
     }
     build(io.tlas_nodes, items);
     io.tlas_pairs.clear();

@@ -11,7 +11,8 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librdr_hip.so")
+# RDR_LIB_PATH: another build of the same library (kernel experiments); there is still no fallback
+LIB_PATH = os.environ.get("RDR_LIB_PATH") or os.path.join(_HERE, "librdr_hip.so")
 
 # every symbol include/rdr_abi.h declares
 ABI_SYMBOLS = [
