@@ -84,10 +84,6 @@ struct rdr_renderer {
     DeviceBuffer<float> srgb_lut;
     DeviceBuffer<uint8_t> shadow;
     DeviceBuffer<uint32_t> pixel_list;
-    DeviceBuffer<float4> shadow_rays;
-    DeviceBuffer<uint32_t> shadow_list_own, shadow_list_world;
-    uint32_t shadow_seg_capacity = 0;
-    uint32_t shadow_split = 1; // measurement hook RDR_SHADOW_SPLIT=0: the single-kernel shadow pass
     DeviceBuffer<FragTri> frag_tri;
     DeviceBuffer<uint32_t> frag_px;
     DeviceBuffer<uint32_t> stat_slots;
@@ -138,7 +134,6 @@ struct rdr_renderer {
     uint32_t frame_seq = 0;
     uint32_t seen_status[2] = {0, 0};
     uint32_t debug_deferred_capacity = 0xFFFFFFFFu; // test hook: smaller deferred list
-    uint32_t list_seen = 0xFFFFFFFFu; // covered-pixel list length the latest finished frame reported (0xFFFFFFFF: none yet)
     uint32_t convex_skip = 1; // measurement hook RDR_CONVEX_SKIP=0: trace every shadow ray through its own instance
 };
 
@@ -370,11 +365,6 @@ FrameView make_frame_view(rdr_renderer* r) {
     fv.pixel_list = r->pixel_list.ptr;
     fv.lds_stack_limit = r->lds_stack_limit;
     fv.convex_skip = r->convex_skip;
-    fv.shadow_rays = r->shadow_rays.ptr;
-    fv.shadow_list_own = r->shadow_list_own.ptr;
-    fv.shadow_list_world = r->shadow_list_world.ptr;
-    fv.shadow_seg_capacity = r->shadow_seg_capacity;
-    fv.shadow_split = r->shadow_split;
     fv.host_status = r->status_dev;
     fv.frame_seq = r->frame_seq & 0xFFFFFFu;
     fv.deferred_capacity = std::min(fv.deferred_capacity, r->debug_deferred_capacity);
@@ -528,15 +518,6 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
     const size_t npx = (size_t)width * height;
     if (r->vis.alloc(npx) || r->color.alloc(npx * 4) || r->counters.alloc(1) || r->shadow.alloc(npx) ||
         r->pixel_list.alloc(npx)) return 1;
-    {
-        // a 256-entry workgroup of the ray set-up always appends to segment blockIdx % 32, and the rays it passes on
-        // stay in that segment: a segment holds what the workgroups mapped to it can produce
-        const size_t groups = (npx + 255) / 256;
-        r->shadow_seg_capacity = (uint32_t)(((groups + kShadowSegments - 1) / kShadowSegments) * 256);
-        const size_t cap = (size_t)r->shadow_seg_capacity * kShadowSegments;
-        if (r->shadow_rays.alloc(npx) || r->shadow_list_own.alloc(cap) || r->shadow_list_world.alloc(cap)) return 1;
-    }
-    if (const char* e = std::getenv("RDR_SHADOW_SPLIT")) r->shadow_split = std::atoi(e) != 0 ? 1u : 0u;
     // depth pyramid: W/2 x H/2 and its mips, a little over a third of a pixel count
     if (r->pyramid.alloc(npx / 2 + width + height + 64)) return 1; // sum over levels <= W*H/3 + W + H + levels
     {
@@ -550,7 +531,6 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
         void* dev = nullptr;
         RDR_HIP(hipHostMalloc(&host, 64, hipHostMallocMapped));
         std::memset(host, 0, 64);
-        static_cast<uint32_t*>(host)[2] = 0xFFFFFFFFu;
         r->status_host = static_cast<volatile uint32_t*>(host);
         RDR_HIP(hipHostGetDevicePointer(&dev, host, 0));
         r->status_dev = static_cast<uint32_t*>(dev);
@@ -753,8 +733,6 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
     RDR_HIP(hipDeviceSynchronize());
     r->has_scene = true;
     r->frame_rendered = false;
-    r->list_seen = 0xFFFFFFFFu;
-    r->status_host[2] = 0xFFFFFFFFu; // the device is idle: no frame is about to report
     return 0;
 }
 
@@ -787,11 +765,6 @@ int rdr_set_partition(rdr_renderer* r, uint32_t instance_lo, uint32_t instance_h
 int rdr_set_shade_rows(rdr_renderer* r, uint32_t row_lo, uint32_t row_hi) {
     RDR_CHECK(r, "rdr_set_shade_rows: renderer is null");
     RDR_CHECK(row_lo <= row_hi, "rdr_set_shade_rows: lo > hi");
-    if (row_lo != r->row_lo || row_hi != r->row_hi) { // list lengths seen so far belong to other rows
-        RDR_HIP(hipStreamSynchronize(r->stream));
-        r->list_seen = 0xFFFFFFFFu;
-        r->status_host[2] = 0xFFFFFFFFu;
-    }
     r->row_lo = row_lo; r->row_hi = row_hi;
     return 0;
 }
@@ -824,14 +797,6 @@ int rdr_shade(rdr_renderer* r) {
     RDR_HIP(hipSetDevice(r->device));
     if (check_finished_frames(r, "rdr_shade")) return 1;
     FrameView fv = make_frame_view(r);
-    {
-        // grid of the shading kernel: the covered-pixel list length the latest finished frame reported for this scene
-        // and these rows (pinned host memory, no synchronisation: a frame still in flight has not reported yet) plus
-        // an eighth; until a frame has reported, the worst case
-        const uint32_t reported = r->status_host[2];
-        if (reported != 0xFFFFFFFFu) r->list_seen = reported;
-        fv.shade_hint_blocks = r->list_seen == 0xFFFFFFFFu ? 0xFFFFFFFFu : (r->list_seen + r->list_seen / 8u + 4096u) / 256u + 1u;
-    }
     fv.list_heads_zero = r->shaded ? 0u : 1u; // first shading pass over this visibility buffer
     hipEvent_t* ev = r->cfg.time_kernels ? r->ring.data() + (size_t)r->cur_slot * rdr_renderer::kEvents : nullptr;
     if (rdr_launch_shade(r->sv, fv, r->stream, ev)) return 1;

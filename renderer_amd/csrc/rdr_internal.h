@@ -130,15 +130,11 @@ struct FrameCounters {
     unsigned long long frag_seg[32 * 32]; // word s * 16: covered pixels (low half) and triangles (high half) of segment s
     uint32_t frag_overflow;
     uint32_t _pad_frag[31];
-    // Shadow rays sorted by what they still have to walk: word s * 16 counts, for segment s, the rays that must
-    // try their own instance's bottom level (low half) and the rays left for the top level (high half).
-    unsigned long long shadow_seg[32 * 16];
 };
 constexpr uint32_t kTileJob = 8; // bin records per job of the tile rasteriser
 constexpr uint32_t kMidSegments = 32;
 constexpr uint32_t kFragSegments = 32;
-constexpr uint32_t kShadowSegments = 32;
-static_assert(sizeof(FrameCounters) == 192 + 4096 + 8192 + 128 + 4096, "FrameCounters layout");
+static_assert(sizeof(FrameCounters) == 192 + 4096 + 8192 + 128, "FrameCounters layout");
 
 struct GpuImage {
     uint32_t width, height, mip_count, format;
@@ -352,16 +348,8 @@ struct FrameView {
     // Frame status in pinned host memory: word 0 is written by the last kernel of the geometry half, word 1 by
     // the last kernel of the shading half, each as frame_seq << 8 | RDR_FRAME_* flags, so that the host learns
     // of dropped work without synchronising (it looks at the words when the next frame is submitted).
-    uint32_t* host_status; // word 2: length of the covered-pixel list of the last shaded frame
+    uint32_t* host_status;
     uint32_t frame_seq;
-    uint32_t shade_hint_blocks; // host side: workgroups of k_shade's grid (from the list lengths of earlier frames)
-    // Split shadow pass: the ray of every listed pixel (origin, draw id) and the two ray lists, each cut into
-    // kShadowSegments segments of shadow_seg_capacity entries.
-    float4* shadow_rays;
-    uint32_t* shadow_list_own;
-    uint32_t* shadow_list_world;
-    uint32_t shadow_seg_capacity;
-    uint32_t shadow_split; // 1: set-up / own instance / top level as three kernels over sorted rays; 0: one kernel per pixel
     uint32_t convex_skip; // 1: shadow rays that leave a closed convex mesh skip that mesh (0 only as a measurement hook)
     // Per-workgroup statistics: every workgroup stores its partial counts in its own
     // slot with plain stores (no contended atomics); the host sums the slots on request.

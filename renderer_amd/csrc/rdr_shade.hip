@@ -10,9 +10,6 @@
 // store, so this file alone is built with the hardware's fast division and square
 // root (a few ulp) instead of the correctly rounded sequences; which pixel shows which
 // triangle, and whether it is in shadow, are decided elsewhere with exact arithmetic.
-#include <algorithm>
-#include <cstdlib>
-
 #include "rdr_pixel.h"
 
 namespace {
@@ -297,35 +294,19 @@ RDR_DEV vec3 shade_pixel(const SceneView& sv, const rdr_ubo& u, uint32_t draw_id
     return color * (shadow_hit ? 0.35f : 1.0f);
 }
 
-// Pass 2: material evaluation, lighting, sRGB store of every covered pixel.
-// The length of the covered-pixel list is only known on the device.  A grid for the worst case (every pixel
-// covered) would mostly start workgroups that find the list exhausted, and at this kernel's register count only
-// three workgroups fit a CU, so retiring tens of thousands of empty ones costs tens of microseconds; a loop over
-// the list inside a small grid costs the kernel its third wave per SIMD (the loop keeps 30 more registers live).
-// So k_shade takes one 256-entry chunk per workgroup on a grid sized from the list length the previous frames
-// reported (FrameView::shade_hint_blocks), and k_shade_rest, a small looping grid, takes whatever lies beyond
-// that grid: nothing, unless the frame covers more pixels than the hint allowed for.
-RDR_DEV void shade_entry(const SceneView& sv, const FrameView& fv, uint32_t entry) {
+// Pass 2: material evaluation, lighting, sRGB store of every covered pixel.  The grid is sized for the worst
+// case (every pixel covered); workgroups beyond the list's end exit on their first load, which costs nothing
+// measurable (a grid cut to the list's length ran in the same time).
+__global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv) {
+    const uint32_t entry = blockIdx.x * 256u + threadIdx.x;
+    if (entry == 0u) // last kernel of the shading half that every frame runs: the frame's status for the host
+        __hip_atomic_store(&fv.host_status[1], (fv.frame_seq << 8) | (fv.counters->deep_overflow ? RDR_FRAME_SHADOW_STACK : 0u),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (entry >= fv.counters->pixel_count) return;
     const ListedPixel p = listed_pixel(sv, fv, entry);
     const vec3 c = shade_pixel(sv, fv.ubo, p.draw_id, p.meshlet, p.tri, p.uvx, p.uvy, fv.shadow[entry] != 0);
     reinterpret_cast<uint32_t*>(fv.color)[p.pi] =
         srgb_encode(c.x) | (srgb_encode(c.y) << 8) | (srgb_encode(c.z) << 16) | (255u << 24);
-}
-
-__global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv) {
-    const uint32_t entry = blockIdx.x * 256u + threadIdx.x;
-    if (entry == 0u) { // last kernel of the shading half that every frame runs: the frame's status for the host
-        __hip_atomic_store(&fv.host_status[1], (fv.frame_seq << 8) | (fv.counters->deep_overflow ? RDR_FRAME_SHADOW_STACK : 0u),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&fv.host_status[2], fv.counters->pixel_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    if (entry >= fv.counters->pixel_count) return;
-    shade_entry(sv, fv, entry);
-}
-
-__global__ __launch_bounds__(256) void k_shade_rest(SceneView sv, FrameView fv, uint32_t first_entry) {
-    const uint32_t count = fv.counters->pixel_count;
-    for (uint32_t entry = first_entry + blockIdx.x * 256u + threadIdx.x; entry < count; entry += gridDim.x * 256u) shade_entry(sv, fv, entry);
 }
 
 // Skybox pass (assets/shaders/cubemap.vert.glsl:41-47, cubemap.frag.glsl:9-12,
@@ -357,9 +338,7 @@ int rdr_launch_shade(const SceneView& sv, const FrameView& fv, hipStream_t strea
     if (fv.row_hi <= fv.row_lo) return 0;
     if (rdr_launch_shadow(sv, fv, stream, ev)) return 1;
     const uint32_t list_blocks = (uint32_t)(((size_t)(fv.row_hi - fv.row_lo) * fv.width + 255u) / 256u);
-    const uint32_t blocks = std::max(1u, std::min(list_blocks, fv.shade_hint_blocks));
-    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, stream, sv, fv);
-    if (blocks < list_blocks) hipLaunchKernelGGL(k_shade_rest, dim3(std::min(list_blocks - blocks, 512u)), dim3(256), 0, stream, sv, fv, blocks * 256u);
+    hipLaunchKernelGGL(k_shade, dim3(list_blocks), dim3(256), 0, stream, sv, fv);
     if (fv.skybox)
         hipLaunchKernelGGL(k_skybox, dim3((fv.width + 63u) / 64u, (fv.row_hi - fv.row_lo + 3u) / 4u), dim3(256), 0, stream, sv, fv);
     if (ev) RDR_HIP(hipEventRecord(ev[9], stream));

@@ -5,19 +5,7 @@
 // renderer/src/renderer/acceleration_sturct_utils.rs:23-49,253-279) becomes a software
 // two-level BVH traversal.  Whether a ray is blocked decides 65 % of a pixel's brightness,
 // so everything here is exact, un-fused IEEE arithmetic, identical to the CPU check.
-#include <algorithm>
-#include <cstdlib>
-
 #include "rdr_pixel.h"
-
-#ifndef RDR_ITER_CAP
-#define RDR_ITER_CAP 0u
-#endif
-#ifndef RDR_WORLD_WAVES
-#define RDR_WORLD_ATTR
-#else
-#define RDR_WORLD_ATTR __attribute__((amdgpu_waves_per_eu(RDR_WORLD_WAVES, RDR_WORLD_WAVES)))
-#endif
 
 namespace {
 
@@ -168,9 +156,7 @@ RDR_DEV bool shadow_any_hit(const SceneView& sv, uint32_t own_instance, bool ski
     uint32_t node_base = skip_own ? sv.tlas_base : sv.instances[own_instance].blas_root, tri_base = sv.instances[own_instance].tri_base;
     uint32_t cur = 0u;
     bool hit = false;
-    uint32_t iters = 0;
     for (;;) {
-        if (RDR_ITER_CAP && ++iters > RDR_ITER_CAP) break;
         if (!(cur & kBvhLeaf)) {
             // one wide node: all its loads are in flight together
             const uint4* q = reinterpret_cast<const uint4*>(sv.bvh + (node_base + cur));
@@ -223,52 +209,6 @@ RDR_DEV bool shadow_any_hit(const SceneView& sv, uint32_t own_instance, bool ski
                 ray = make_ray(o, d, tmax);
                 node_base = sv.tlas_base;
             }
-            if (st.sp == 0) break;
-            cur = st.pop();
-        }
-    }
-    return hit;
-}
-
-// One instance's bottom level on its own: the walk of shadow_any_hit without the top level.
-template <typename Stack>
-RDR_DEV bool blas_any_hit(const SceneView& sv, const GpuInstance& inst, vec3 o, vec3 d, float tmin, float tmax, Stack& st) {
-    st.sp = 0;
-    st.overflow = false;
-    const Ray ray = object_ray(inst, o, d, tmax);
-    const uint32_t node_base = inst.blas_root, tri_base = inst.tri_base;
-    uint32_t cur = 0u;
-    bool hit = false;
-    uint32_t iters = 0;
-    for (;;) {
-        if (RDR_ITER_CAP && ++iters > RDR_ITER_CAP) break;
-        if (!(cur & kBvhLeaf)) {
-            const uint4* q = reinterpret_cast<const uint4*>(sv.bvh + (node_base + cur));
-            const uint4 codes = q[0], bx = q[1], by = q[2], bz = q[3];
-            const uint32_t code[4] = {codes.x, codes.y, codes.z, codes.w};
-            const uint32_t wx[4] = {bx.x, bx.y, bx.z, bx.w}, wy[4] = {by.x, by.y, by.z, by.w}, wz[4] = {bz.x, bz.y, bz.z, bz.w};
-            cur = kBvhNone;
-            float cur_exit = -1.0e30f;
-#pragma unroll
-            for (int i = 0; i < kBvhWidth; ++i) { // the child the ray leaves last goes first, as in shadow_any_hit
-                float t_exit;
-                const bool h = (code[i] != kBvhNone) & ray_box(wx[i], wy[i], wz[i], ray.slab, tmin, tmax, t_exit);
-                const bool take = h & (t_exit >= cur_exit);
-                st.push_if(h & (cur != kBvhNone), take ? cur : code[i]);
-                cur = take ? code[i] : cur;
-                cur_exit = take ? t_exit : cur_exit;
-            }
-        }
-        if ((cur & kBvhLeaf) && cur != kBvhNone) {
-            const uint32_t count = (cur >> 24) & 127u, first = cur & 0xFFFFFFu;
-            cur = kBvhNone;
-            const float* tp = sv.blas_tris + (size_t)(tri_base + first) * 9;
-#pragma clang loop vectorize(disable)
-            for (uint32_t i = 0; i < count; ++i, tp += 9)
-                hit |= ray_triangle(ray.o, ray.d, mk3(tp[0], tp[1], tp[2]), mk3(tp[3], tp[4], tp[5]), mk3(tp[6], tp[7], tp[8]), tmin, tmax);
-        }
-        if (hit) break;
-        if (cur == kBvhNone) {
             if (st.sp == 0) break;
             cur = st.pop();
         }
@@ -396,126 +336,6 @@ __global__ __launch_bounds__(256) void k_shadow(SceneView sv, FrameView fv) {
     fv.shadow[entry] = hit;
 }
 
-// ---- the shadow pass as three kernels over sorted rays ---------------------------------------------
-// A wave of k_shadow above waits for its slowest lane, and the lanes differ in kind: rays that may skip
-// their own instance, rays that hit it at once, rays that walk it in vain and go on to the top level.
-// Here every kernel does one kind of work on full waves: k_shadow_setup computes each listed pixel's ray
-// and sorts it into "own instance first" or "top level only"; k_shadow_own walks the own bottom level
-// and passes the rays that found nothing on; k_shadow_world walks the top level and the other instances.
-// The lists are cut into kShadowSegments segments; a workgroup appends to segment blockIdx % 32 with one
-// atomic (same-address atomics that return a value serialise) and consumers take workgroup b's 256
-// entries from segment b % 32, so a ray stays in its segment and a segment's capacity is what the set-up
-// workgroups mapped to it can produce.
-struct ListAppend {
-    uint32_t wave_n[4];
-    unsigned long long base;
-};
-
-// Appends `entry` of every thread with `pred` to segment `seg` of `list`; `high`: the list counted in the
-// high half of the segment's counter.  All 256 threads of the workgroup call it.
-RDR_DEV void append_to_segment(const FrameView& fv, ListAppend& la, uint32_t* list, uint32_t seg, bool high, bool pred, uint32_t entry) {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const unsigned long long m = __ballot(pred);
-    if (lane == 0) la.wave_n[wave] = (uint32_t)__popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t n = la.wave_n[0] + la.wave_n[1] + la.wave_n[2] + la.wave_n[3];
-        unsigned long long old = 0;
-        if (n) old = atomicAdd(&fv.counters->shadow_seg[seg * 16u], high ? ((unsigned long long)n << 32) : (unsigned long long)n);
-        la.base = high ? (old >> 32) : (old & 0xFFFFFFFFull);
-    }
-    __syncthreads();
-    if (pred) {
-        uint32_t slot = (uint32_t)la.base + ballot_rank(m);
-        for (uint32_t w = 0; w < wave; ++w) slot += la.wave_n[w];
-        if (slot < fv.shadow_seg_capacity) list[(size_t)seg * fv.shadow_seg_capacity + slot] = entry;
-    }
-    __syncthreads(); // la is reused by the next call
-}
-
-// The three kernels are persistent: a grid of about one resident round whose workgroups loop over 256-entry
-// chunks.  Launched per chunk for the worst case (every pixel covered), most workgroups would find nothing to do, and
-// starting and retiring tens of thousands of empty workgroups costs more than the rays of a sparsely covered frame.
-__global__ __launch_bounds__(256) void k_shadow_setup(SceneView sv, FrameView fv) {
-    __shared__ ListAppend la;
-    const uint32_t count = fv.counters->pixel_count;
-    const rdr_ubo& u = fv.ubo;
-    const vec3 L = normalize3(mk3(u.sun_direction[0], u.sun_direction[1], u.sun_direction[2]));
-    for (uint32_t chunk = blockIdx.x; chunk * 256u < count; chunk += gridDim.x) {
-        const uint32_t entry = chunk * 256u + threadIdx.x;
-        const bool valid = entry < count;
-        bool skip_own = false;
-        if (valid) {
-            const ListedPixel p = listed_pixel(sv, fv, entry);
-            vec3 face_normal;
-            const vec3 w_pos = pixel_world_position(sv, fv.ubo, p.draw_id, p.meshlet, p.tri, p.uvx, p.uvy, face_normal);
-            skip_own = fv.convex_skip && leaves_convex_mesh(sv, p.draw_id, face_normal, L);
-            fv.shadow_rays[entry] = make_float4(w_pos.x, w_pos.y, w_pos.z, __uint_as_float(p.draw_id));
-        }
-        const uint32_t seg = chunk % kShadowSegments;
-        append_to_segment(fv, la, fv.shadow_list_own, seg, false, valid && !skip_own, entry);
-        append_to_segment(fv, la, fv.shadow_list_world, seg, true, valid && skip_own, entry);
-    }
-}
-
-// own / world: the grid is a multiple of kShadowSegments, so a workgroup stays with segment blockIdx % 32 and walks
-// its chunks a grid's width apart.  The traversal stack is dynamic LDS, (limit + 1) rows of 256 entries.
-__global__ __launch_bounds__(256) void k_shadow_own(SceneView sv, FrameView fv, int stack_limit) {
-    extern __shared__ uint32_t stack_mem[];
-    __shared__ ListAppend la;
-    const uint32_t seg = blockIdx.x % kShadowSegments, stride = gridDim.x / kShadowSegments;
-    const uint32_t n = min((uint32_t)(fv.counters->shadow_seg[seg * 16u] & 0xFFFFFFFFull), fv.shadow_seg_capacity);
-    const rdr_ubo& u = fv.ubo;
-    const vec3 L = normalize3(mk3(u.sun_direction[0], u.sun_direction[1], u.sun_direction[2]));
-    for (uint32_t chunk = blockIdx.x / kShadowSegments; chunk * 256u < n; chunk += stride) {
-        const uint32_t i = chunk * 256u + threadIdx.x;
-        const bool valid = i < n;
-        bool pass_on = false;
-        uint32_t entry = 0;
-        if (valid) {
-            entry = fv.shadow_list_own[(size_t)seg * fv.shadow_seg_capacity + i];
-            const float4 ray = fv.shadow_rays[entry];
-            LdsStack st;
-            st.base = stack_mem + threadIdx.x;
-            st.limit = stack_limit;
-            const bool h = blas_any_hit(sv, sv.instances[__float_as_uint(ray.w)], mk3(ray.x, ray.y, ray.z), L, 1e-2f, 1000.0f, st);
-            if (h) {
-                fv.shadow[entry] = 1;
-            } else if (st.overflow) { // a miss that dropped stack entries proves nothing: leave the whole ray to k_shadow_deep
-                fv.shadow[entry] = 2;
-                atomicAdd(&fv.counters->shadow_overflow, 1u);
-            } else {
-                pass_on = true;
-            }
-        }
-        append_to_segment(fv, la, fv.shadow_list_world, seg, true, pass_on, entry);
-    }
-}
-
-__global__ __launch_bounds__(256) RDR_WORLD_ATTR void k_shadow_world(SceneView sv, FrameView fv, int stack_limit) {
-    extern __shared__ uint32_t stack_mem[];
-    const uint32_t seg = blockIdx.x % kShadowSegments, stride = gridDim.x / kShadowSegments;
-    const uint32_t n = min((uint32_t)(fv.counters->shadow_seg[seg * 16u] >> 32), fv.shadow_seg_capacity);
-    const rdr_ubo& u = fv.ubo;
-    const vec3 L = normalize3(mk3(u.sun_direction[0], u.sun_direction[1], u.sun_direction[2]));
-    for (uint32_t chunk = blockIdx.x / kShadowSegments; chunk * 256u < n; chunk += stride) {
-        const uint32_t i = chunk * 256u + threadIdx.x;
-        if (i >= n) continue;
-        const uint32_t entry = fv.shadow_list_world[(size_t)seg * fv.shadow_seg_capacity + i];
-        const float4 ray = fv.shadow_rays[entry];
-        LdsStack st;
-        st.base = stack_mem + threadIdx.x;
-        st.limit = stack_limit;
-        const bool h = shadow_any_hit(sv, __float_as_uint(ray.w), true, mk3(ray.x, ray.y, ray.z), L, 1e-2f, 1000.0f, st);
-        uint8_t hit = h ? 1 : 0;
-        if (!h && st.overflow) {
-            hit = 2;
-            atomicAdd(&fv.counters->shadow_overflow, 1u);
-        }
-        fv.shadow[entry] = hit;
-    }
-}
-
 // Pass 1b: pixels whose traversal overflowed the LDS stack, traced again with the deep
 // scratch-backed stack.  Exits at once when there are none (the normal case).
 __global__ __launch_bounds__(256) void k_shadow_deep(SceneView sv, FrameView fv) {
@@ -546,27 +366,10 @@ int rdr_launch_shadow(const SceneView& sv, const FrameView& fv, hipStream_t stre
     if (ev) RDR_HIP(hipEventRecord(ev[6], stream));
     // pixel_count, shadow_overflow: zeroed by the geometry pass's clear; only a second shading pass over the
     // same visibility buffer has to reset them (a memset between kernels is a 4 us kernel of its own)
-    if (!fv.list_heads_zero) {
-        RDR_HIP(hipMemsetAsync(&fv.counters->pixel_count, 0, 2 * sizeof(uint32_t), stream));
-        RDR_HIP(hipMemsetAsync(fv.counters->shadow_seg, 0, sizeof(fv.counters->shadow_seg), stream));
-    }
+    if (!fv.list_heads_zero) RDR_HIP(hipMemsetAsync(&fv.counters->pixel_count, 0, 2 * sizeof(uint32_t), stream));
     hipLaunchKernelGGL(k_classify, tiles, dim3(1024), 0, stream, fv);
     if (ev) RDR_HIP(hipEventRecord(ev[7], stream));
-    if (fv.shadow_split) {
-        // consumers: workgroup b takes 256 entries of segment b % 32; launched for the worst case, exits beyond the counts
-        // persistent grids: about one resident round (a multiple of the segment count), never more than the worst case needs
-        static const uint32_t round_env = getenv("RDR_SHADOW_GRID") ? (uint32_t)atoi(getenv("RDR_SHADOW_GRID")) : 2048u;
-        const uint32_t worst = kShadowSegments * ((list_blocks + kShadowSegments - 1u) / kShadowSegments);
-        const uint32_t seg_blocks = std::max(kShadowSegments, std::min(worst, round_env / kShadowSegments * kShadowSegments));
-        hipLaunchKernelGGL(k_shadow_setup, dim3(std::min(list_blocks, round_env)), dim3(256), 0, stream, sv, fv);
-        static const int own_env = getenv("RDR_OWN_STACK") ? atoi(getenv("RDR_OWN_STACK")) : 16;
-        static const int world_env = getenv("RDR_WORLD_STACK") ? atoi(getenv("RDR_WORLD_STACK")) : 24;
-        const int own_limit = std::min((int)fv.lds_stack_limit, own_env), world_limit = std::min((int)fv.lds_stack_limit, world_env);
-        hipLaunchKernelGGL(k_shadow_own, dim3(seg_blocks), dim3(256), (size_t)(own_limit + 1) * 1024, stream, sv, fv, own_limit);
-        hipLaunchKernelGGL(k_shadow_world, dim3(seg_blocks), dim3(256), (size_t)(world_limit + 1) * 1024, stream, sv, fv, world_limit);
-    } else {
-        hipLaunchKernelGGL(k_shadow, dim3(list_blocks), dim3(256), 0, stream, sv, fv);
-    }
+    hipLaunchKernelGGL(k_shadow, dim3(list_blocks), dim3(256), 0, stream, sv, fv);
     hipLaunchKernelGGL(k_shadow_deep, dim3(512), dim3(256), 0, stream, sv, fv);
     if (ev) RDR_HIP(hipEventRecord(ev[8], stream));
     RDR_HIP(hipGetLastError());
