@@ -174,8 +174,9 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=40, help="CPU-baseline frames, about 10 s of CPU work (0 = skip)")
     ap.add_argument("--secondary-frames", type=int, default=50,
                     help="single GPU only: frames for the secondary series (LOD on, alpha-masked, atrium); 0 = skip")
-    ap.add_argument("--composite", choices=("auto", "reduce_scatter", "all_reduce"), default="auto",
-                    help="exchange step of the sort-last composite (auto: reduce-scatter on RCCL)")
+    ap.add_argument("--composite", choices=("auto", "p2p", "reduce_scatter", "all_reduce"), default="auto",
+                    help="exchange step of the sort-last composite (auto: the library's peer-to-peer exchange over xGMI when "
+                         "the ranks can open each other's buffers and a probe frame matches the collective, else RCCL reduce-scatter)")
     ap.add_argument("--frames-in-flight", type=int, default=int(os.environ.get("RDR_FRAMES_IN_FLIGHT", "2")),
                     help="multi-GPU only: renderers taking turns so that one frame's exchange overlaps the next frame's raster")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
@@ -255,6 +256,8 @@ def main():
         step()
     torch.cuda.synchronize()
     r.stats()  # drop the warm-up frames from the kernel timers
+    if frame is not None:
+        frame.time_composite()  # device time stamps around the exchange and the gather of the timed frames
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
@@ -270,6 +273,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = r.stats()  # counters of the last frame + mean kernel times over the timed frames
+    composite_ms = frame.composite_ms() if frame is not None else None
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -315,7 +319,7 @@ def main():
                 "instances": total_instances, "width": W, "height": H,
                 "ranks": dist.get_world_size() if multi else 1, "backend": (dist.get_backend() if multi else None),
                 "parallelism": "single GPU" if frame is None else
-                               f"sort-last x{world}, u64-min {frame.composite.replace('_', '-')} + row-split shade + RGBA8 all-gather, "
+                               f"sort-last x{world}, u64-min {frame.composite.replace('_', '-')} + row-split shade + RGBA8 row gather, "
                                f"{len(frame.slots)} frames in flight" + ("" if args.backend == "nccl" else " [gloo rehearsal]"),
             },
             "kernel_ms": {k: round(v, 4) for k, v in kms.items() if v > 0},
@@ -330,6 +334,8 @@ def main():
                          # not memory-bound: what it is bound by instead (PMC passes of profiles/pmc_passes.sh)
                          "valu_issue": issue},
         }
+        if composite_ms is not None:  # device time of the exchange steps (rank 0, mean per frame; overlapped with the other slot's raster)
+            out["composite_ms"] = {"keys": round(composite_ms[0], 4), "rows": round(composite_ms[1], 4), "form": frame.composite}
         raster_s = (kms["raster"] + kms["big_raster"]) * 1e-3
         if raster_s > 0:  # the rasteriser's own roofline is the L2 atomic rate (per-lane and per-wave scans issue one per fragment)
             out["raster_atomics"] = {"fragments": st["fragments"], "per_s": st["fragments"] / raster_s,

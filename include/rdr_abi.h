@@ -336,6 +336,42 @@ int rdr_set_shade_rows(rdr_renderer* r, uint32_t row_lo, uint32_t row_hi);
 void* rdr_visbuffer_device_ptr(rdr_renderer* r);
 void* rdr_color_device_ptr(rdr_renderer* r);
 
+/* ------------------------------------------------------------------ */
+/* Sort-last exchange, peer to peer over xGMI (no counterpart in the    */
+/* reference, which is single-GPU).  One process per GPU; every rank     */
+/* holds the whole scene, rasterises its rdr_set_partition share into a  */
+/* full-frame visibility buffer and shades the rows of                    */
+/* rdr_set_shade_rows.  Instead of a ring collective, each rank reads    */
+/* the keys of its own rows straight out of every peer's buffer (shared  */
+/* through HIP IPC handles) and takes the 64-bit minimum, which is       */
+/* bit-identical to a uint64 MIN all-reduce restricted to those rows;    */
+/* the shaded RGBA8 rows are then written straight into every peer's     */
+/* image.  Per frame on every rank, in this order and on the renderer's  */
+/* stream, without host synchronisation in between:                       */
+/*   rdr_render_visbuffer, rdr_composite_exchange, rdr_shade,            */
+/*   rdr_composite_gather.                                                */
+/* Ranks are ordered against each other by phase counters in device      */
+/* memory; a rank whose peer does not arrive within 5 s gets an error    */
+/* from its next call instead of a hang.  Rows must be a partition of    */
+/* the image among the ranks; width x rows of every strip must be a      */
+/* multiple of four pixels.                                               */
+/* ------------------------------------------------------------------ */
+#define RDR_COMPOSITE_MAX_RANKS 16
+typedef struct rdr_composite_handle { /* three hipIpcMemHandle_t: keys, image, control block */
+    uint8_t vis[64];
+    uint8_t color[64];
+    uint8_t ctrl[64];
+} rdr_composite_handle;
+/* This renderer's handles, to be sent to every other rank (any transport: a file, MPI, a socket). */
+int rdr_composite_export(rdr_renderer* r, rdr_composite_handle* out);
+/* handles[world]: every rank's export in rank order (handles[rank] is not read).  Collective in the
+ * sense that every rank must connect before any rank's first exchange completes. */
+int rdr_composite_connect(rdr_renderer* r, uint32_t rank, uint32_t world, const rdr_composite_handle* handles);
+int rdr_composite_exchange(rdr_renderer* r);
+int rdr_composite_gather(rdr_renderer* r);
+/* Waits for this renderer's work, then closes the peers' buffers.  Call on every rank before rdr_destroy. */
+int rdr_composite_disconnect(rdr_renderer* r);
+
 /* Run on the caller's HIP stream (hipStream_t) instead of the library's own.  NULL goes back to the
  * library's own (non-blocking) stream; to select HIP's null stream pass hipStreamLegacy, HIP's handle
  * for it ((hipStream_t)1), which like hipStreamPerThread is handed to the runtime unchanged. */

@@ -134,6 +134,7 @@ struct rdr_renderer {
     uint32_t frame_seq = 0;
     uint32_t seen_status[2] = {0, 0};
     uint32_t debug_deferred_capacity = 0xFFFFFFFFu; // test hook: smaller deferred list
+    rdr_composite_state* composite = nullptr; // peer-to-peer sort-last exchange, created on first use
     uint32_t convex_skip = 1; // measurement hook RDR_CONVEX_SKIP=0: trace every shadow ray through its own instance
 };
 
@@ -555,6 +556,7 @@ void rdr_destroy(rdr_renderer* r) {
     for (auto& e : r->ring) (void)hipEventDestroy(e);
     if (r->own_stream) (void)hipStreamDestroy(r->own_stream);
     if (r->status_host) (void)hipHostFree(const_cast<uint32_t*>(r->status_host));
+    rdr_composite_destroy(r->composite);
     delete r;
 }
 
@@ -808,6 +810,46 @@ int rdr_shade(rdr_renderer* r) {
 int rdr_render(rdr_renderer* r, const float cam_pos[3], const float cam_dir[3], const float sun_dir[3]) {
     if (rdr_render_visbuffer(r, cam_pos, cam_dir, sun_dir)) return 1;
     return rdr_shade(r);
+}
+
+int rdr_composite_export(rdr_renderer* r, rdr_composite_handle* out) {
+    RDR_CHECK(r && out, "rdr_composite_export: null argument");
+    RDR_HIP(hipSetDevice(r->device));
+    if (!r->composite && rdr_composite_create(&r->composite)) return 1;
+    return rdr_composite_export_handles(r->composite, r->vis.ptr, r->color.ptr, out);
+}
+
+int rdr_composite_connect(rdr_renderer* r, uint32_t rank, uint32_t world, const rdr_composite_handle* handles) {
+    RDR_CHECK(r && handles, "rdr_composite_connect: null argument");
+    RDR_CHECK(r->composite, "rdr_composite_connect: call rdr_composite_export first (the peers need this rank's handles too)");
+    RDR_HIP(hipSetDevice(r->device));
+    return rdr_composite_open(r->composite, rank, world, handles, r->vis.ptr, r->color.ptr);
+}
+
+int rdr_composite_exchange(rdr_renderer* r) {
+    RDR_CHECK(r && r->composite, "rdr_composite_exchange: not connected");
+    RDR_CHECK(r->frame_rendered, "rdr_composite_exchange: no visibility buffer rendered yet");
+    RDR_HIP(hipSetDevice(r->device));
+    if (rdr_composite_check(r->composite, "rdr_composite_exchange")) return 1;
+    return rdr_composite_launch_exchange(r->composite, r->width, std::min(r->row_lo, r->height), std::min(r->row_hi, r->height), r->stream);
+}
+
+int rdr_composite_gather(rdr_renderer* r) {
+    RDR_CHECK(r && r->composite, "rdr_composite_gather: not connected");
+    RDR_CHECK(r->shaded, "rdr_composite_gather: nothing shaded yet");
+    RDR_HIP(hipSetDevice(r->device));
+    if (rdr_composite_check(r->composite, "rdr_composite_gather")) return 1;
+    return rdr_composite_launch_gather(r->composite, r->width, std::min(r->row_lo, r->height), std::min(r->row_hi, r->height), r->stream);
+}
+
+int rdr_composite_disconnect(rdr_renderer* r) {
+    RDR_CHECK(r, "rdr_composite_disconnect: renderer is null");
+    if (!r->composite) return 0;
+    RDR_HIP(hipSetDevice(r->device));
+    RDR_HIP(hipStreamSynchronize(r->stream));
+    const int rc = rdr_composite_check(r->composite, "rdr_composite_disconnect");
+    rdr_composite_close(r->composite);
+    return rc;
 }
 
 int rdr_frame_status(rdr_renderer* r, uint32_t* flags) {

@@ -382,6 +382,16 @@ struct GeometryResidency {
 int rdr_geometry_residency(GeometryResidency* out);
 int rdr_launch_shadow(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev); // classify + shadow rays
 int rdr_launch_shade(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev);  // the above, then k_shade
+// ---- peer-to-peer sort-last exchange (rdr_composite.hip) ----------------------------
+struct rdr_composite_state;
+int rdr_composite_create(rdr_composite_state** out);
+void rdr_composite_close(rdr_composite_state* c);
+void rdr_composite_destroy(rdr_composite_state* c);
+int rdr_composite_export_handles(rdr_composite_state* c, void* vis, void* color, rdr_composite_handle* out);
+int rdr_composite_open(rdr_composite_state* c, uint32_t rank, uint32_t world, const rdr_composite_handle* handles, void* vis, void* color);
+int rdr_composite_check(rdr_composite_state* c, const char* who);
+int rdr_composite_launch_exchange(rdr_composite_state* c, uint32_t width, uint32_t row_lo, uint32_t row_hi, hipStream_t stream);
+int rdr_composite_launch_gather(rdr_composite_state* c, uint32_t width, uint32_t row_lo, uint32_t row_hi, hipStream_t stream);
 size_t rdr_bc_level_bytes(uint32_t format, uint32_t width, uint32_t height);
 int rdr_launch_decode_bc(uint32_t format, uint32_t width, uint32_t height, const uint8_t* blocks, uint32_t* out, hipStream_t stream);
 int rdr_launch_resolve(const SceneView& sv, const FrameView& fv, uint32_t* out_xy, hipStream_t stream);

@@ -7,12 +7,19 @@ visibility buffer, and the buffers are composited with one 64-bit MIN reduction:
 associative and commutative and the clear value is its identity, so the result is bit-identical
 to the single-GPU buffer.  Keys never set bit 63, hence MIN over int64 (supported by every
 backend, gloo included) equals the unsigned 64-bit min.  Each rank then shades H/N rows and the
-RGBA8 rows are all-gathered (half the bytes of gathering keys).
+RGBA8 rows are gathered (half the bytes of gathering keys).
 
-A rank only ever reads the composited keys of the rows it shades, so on RCCL the reduction runs
-as a reduce-scatter (the first half of a ring all-reduce: (N-1)/N of the buffer per rank instead
-of twice that); the full all-reduce stays available (``composite="all_reduce"``) and is what
-backends without reduce-scatter (gloo) use.
+Three forms of the exchange step, chosen once when a frame object is built:
+
+``p2p``             the library's own peer-to-peer exchange (``rdr_composite_*``): each rank reads the keys of
+                    its rows straight out of every peer's buffer over xGMI and takes the minimum, then writes
+                    its shaded rows straight into every peer's image.  xGMI is point to point (seven links per
+                    GPU), so this uses all links at once where a ring moves every byte over one link per hop.
+``reduce_scatter``  RCCL MIN reduce-scatter by row strips + all-gather of the rows.
+``all_reduce``      RCCL / gloo MIN all-reduce of the whole buffer + all-gather (the only form gloo offers).
+
+``auto`` takes ``p2p`` when every rank could open every peer's buffers and a probe frame composited that way
+equals the collective's result on every rank, else ``reduce_scatter`` where the backend has it, else ``all_reduce``.
 """
 import torch
 import torch.distributed as dist
@@ -48,7 +55,7 @@ def composite_min(vis_i64):
 def composite_min_rows(vis_i64, height, rank, world):
     """MIN reduce-scatter by row strips: afterwards ``vis_i64`` holds the composited keys in this
     rank's rows (the rest of the buffer is not meaningful).  Needs equal strips and a backend
-    with reduce-scatter; callers fall back to :func:`composite_min` otherwise."""
+    with reduce-scatter."""
     assert vis_i64.dtype == torch.int64 and height % world == 0
     flat = vis_i64.view(-1)
     strip = flat.numel() // world
@@ -57,18 +64,16 @@ def composite_min_rows(vis_i64, height, rank, world):
     return vis_i64
 
 
-def gather_rows(color, rank, world):
-    """All-gather the row strips each rank shaded into the full (H, W, 4) uint8 image, in place."""
+def gather_rows(color, rank, world, in_place=True):
+    """All-gather the row strips each rank shaded into the full (H, W, 4) uint8 image."""
     height = color.shape[0]
     bounds = [row_range(height, k, world) for k in range(world)]
     sizes = {hi - lo for lo, hi in bounds}
     lo, hi = bounds[rank]
     if len(sizes) == 1 and dist.get_backend() == "nccl":
         # equal strips: this rank's rows already sit at their offset of the output buffer (RCCL's in-place form)
-        try:
-            dist.all_gather_into_tensor(color.view(-1), color[lo:hi].reshape(-1))
-        except (RuntimeError, ValueError):  # argument check refused the aliasing: same on every rank
-            dist.all_gather_into_tensor(color.view(-1), color[lo:hi].reshape(-1).clone())
+        mine = color[lo:hi].reshape(-1)
+        dist.all_gather_into_tensor(color.view(-1), mine if in_place else mine.clone())
     elif _host_staged(color):
         parts = [torch.empty((b - a,) + tuple(color.shape[1:]), dtype=color.dtype) for a, b in bounds]
         dist.all_gather(parts, color[lo:hi].cpu())
@@ -80,6 +85,40 @@ def gather_rows(color, rank, world):
     return color
 
 
+def _all_agree(ok):
+    """True when ``ok`` holds on every rank (a MIN all-reduce of one flag)."""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+def probe_collectives(device_tensors, height, world):
+    """Which in-place collective forms this backend build accepts, found once on scratch tensors (the frame loop
+    must not discover a refused form while other ranks have already enqueued theirs).  Returns
+    (reduce_scatter_ok, in_place_gather_ok); every rank gets the same answer."""
+    if dist.get_backend() != "nccl" or not device_tensors or height % world:
+        return False, False
+    rank = dist.get_rank()
+    scratch = torch.zeros(world * 16, dtype=torch.int64, device="cuda")
+    try:
+        dist.reduce_scatter_tensor(scratch[rank * 16:(rank + 1) * 16], scratch, op=dist.ReduceOp.MIN)
+        torch.cuda.synchronize()
+        scatter = True
+    except (RuntimeError, ValueError):
+        scatter = False
+    scatter = _all_agree(scatter)
+    img = torch.zeros(world * 16, dtype=torch.uint8, device="cuda")
+    try:
+        dist.all_gather_into_tensor(img, img[rank * 16:(rank + 1) * 16])
+        torch.cuda.synchronize()
+        gather = True
+    except (RuntimeError, ValueError):
+        gather = False
+    return scatter, _all_agree(gather)
+
+
 class SortLastFrame:
     """One frame on ``world`` ranks around any renderer exposing set_partition /
     set_shade_rows / render_visbuffer / shade (the HIP ``Renderer`` with device tensors, or the
@@ -88,14 +127,46 @@ class SortLastFrame:
     def __init__(self, renderer, n_instances, height, rank, world, vis_tensor, color_tensor, composite="auto"):
         self.r, self.rank, self.world, self.height = renderer, rank, world, height
         self.vis, self.color = vis_tensor, color_tensor
-        if composite == "auto":
-            scatter_ok = dist.get_backend() == "nccl" and height % world == 0
-            composite = "reduce_scatter" if scatter_ok else "all_reduce"
-        assert composite in ("reduce_scatter", "all_reduce")
-        self.composite = composite
+        assert composite in ("auto", "p2p", "reduce_scatter", "all_reduce")
         renderer.set_partition(*instance_range(n_instances, rank, world))
         renderer.set_shade_rows(*row_range(height, rank, world))
         self._stream_handle = None
+        self.timing = None  # list of four events per frame once time_composite() was called
+        device = bool(getattr(vis_tensor, "is_cuda", False))
+        scatter_ok, self._gather_in_place = probe_collectives(device, height, world)
+        self._p2p = False
+        if composite in ("auto", "p2p") and device and hasattr(renderer, "composite_export"):
+            self._p2p = self._connect_p2p()
+            if composite == "p2p" and not self._p2p:
+                raise RuntimeError("composite='p2p': the ranks could not open each other's buffers")
+        if self._p2p:
+            self.composite = "p2p"
+        elif composite in ("auto", "p2p", "reduce_scatter") and scatter_ok:
+            self.composite = "reduce_scatter"
+        else:
+            self.composite = "all_reduce"
+
+    def _connect_p2p(self):
+        """Exchange IPC handles and open every peer's buffers; all ranks take the same decision."""
+        handles, ok = [None] * self.world, True
+        try:
+            mine = self.r.composite_export()
+        except Exception:
+            mine, ok = b"", False
+        dist.all_gather_object(handles, mine)
+        ok = ok and all(len(h) == len(mine) and len(h) > 0 for h in handles)
+        if _all_agree(ok):
+            try:
+                self.r.composite_connect(self.rank, self.world, handles)
+            except Exception:
+                ok = False
+            if _all_agree(ok):
+                return True
+            try:
+                self.r.composite_disconnect()
+            except Exception:
+                pass
+        return False
 
     def _follow_current_stream(self):
         """The collectives run on torch's current stream: the renderer's kernels must be ordered on
@@ -108,32 +179,66 @@ class SortLastFrame:
             self.r.set_stream(handle)
             self._stream_handle = handle
 
+    def time_composite(self):
+        """Start recording device-side time stamps around the exchange and the gather of every frame."""
+        self.timing = []
+
+    def composite_ms(self):
+        """Mean device time of (key exchange, row gather) per recorded frame; synchronises."""
+        if not self.timing:
+            return None
+        torch.cuda.synchronize()
+        ex = sum(a.elapsed_time(b) for a, b, _, _ in self.timing) / len(self.timing)
+        ga = sum(c.elapsed_time(d) for _, _, c, d in self.timing) / len(self.timing)
+        self.timing = []
+        return ex, ga
+
     def step(self, camera=None, sun=None):
         self._follow_current_stream()
+        ev = None
+        if self.timing is not None and getattr(self.vis, "is_cuda", False):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         self.r.render_visbuffer(camera, sun)
-        if self.composite == "reduce_scatter":
-            try:
-                composite_min_rows(self.vis, self.height, self.rank, self.world)
-            except (RuntimeError, ValueError):
-                # a backend build that refuses the in-place form raises while checking its arguments, on
-                # every rank alike and before anything is enqueued: all ranks switch to the all-reduce
-                self.composite = "all_reduce"
-                composite_min(self.vis)
+        if ev:
+            ev[0].record()
+        if self.composite == "p2p":
+            self.r.composite_exchange()
+        elif self.composite == "reduce_scatter":
+            composite_min_rows(self.vis, self.height, self.rank, self.world)
         else:
             composite_min(self.vis)
+        if ev:
+            ev[1].record()
         self.r.shade()
-        gather_rows(self.color, self.rank, self.world)
+        if ev:
+            ev[2].record()
+        if self.composite == "p2p":
+            self.r.composite_gather()
+        else:
+            gather_rows(self.color, self.rank, self.world, self._gather_in_place)
+        if ev:
+            ev[3].record()
+            self.timing.append(tuple(ev))
+
+    def close(self):
+        if self._p2p:
+            if getattr(self.vis, "is_cuda", False):
+                torch.cuda.synchronize()
+            dist.barrier()  # no rank unmaps buffers a peer may still be reading
+            self.r.composite_disconnect()
+            self._p2p = False
 
 
 class SortLastPipeline:
     """Several frames in flight on one rank: ``depth`` renderers (each with its own buffers and
     its own HIP stream) take turns, so that frame i+1 is rasterised while frame i's keys and
     colour rows are on the links.  The host never waits inside :meth:`step`; every rank issues
-    the same collectives in the same order, and a slot's stream orders its reuse.
+    the same exchanges in the same order, and a slot's stream orders its reuse.
 
-    ``make_renderer`` builds a HIP ``Renderer`` with the scene already set."""
+    ``make_renderer`` builds a HIP ``Renderer`` with the scene already set.  With ``composite="auto"`` a probe
+    frame decides between the peer-to-peer exchange and the collectives (see the module docstring)."""
 
-    def __init__(self, make_renderer, n_instances, height, rank, world, depth=2, composite="auto"):
+    def __init__(self, make_renderer, n_instances, height, rank, world, depth=2, composite="auto", verify=True):
         self.slots = []
         for _ in range(max(1, depth)):
             r = make_renderer()
@@ -142,10 +247,33 @@ class SortLastPipeline:
             color = torch.as_tensor(r.color_device_array(), device="cuda")
             self.slots.append((SortLastFrame(r, n_instances, height, rank, world, vis, color, composite), stream))
         self.issued = 0
+        if verify and composite == "auto" and self.composite == "p2p" and not self._p2p_matches_collective(height, rank, world):
+            # the direct exchange is not trusted on this machine: every slot goes back to the collectives
+            scatter_ok, _ = probe_collectives(True, height, world)
+            for f, _ in self.slots:
+                f.close()
+                f.composite = "reduce_scatter" if scatter_ok else "all_reduce"
+
+    def _p2p_matches_collective(self, height, rank, world):
+        """One frame composited both ways on slot 0: the keys of this rank's rows and the gathered image must be
+        identical on every rank."""
+        f, stream = self.slots[0]
+        lo, hi = row_range(height, rank, world)
+        with torch.cuda.stream(stream):
+            f.step()
+            torch.cuda.synchronize()
+            keys = f.vis.view(height, -1)[lo:hi].clone()
+            image = f.color.clone()
+            f.composite = "all_reduce"
+            f.step()
+            torch.cuda.synchronize()
+            same = bool(torch.equal(keys, f.vis.view(height, -1)[lo:hi])) and bool(torch.equal(image, f.color))
+            f.composite = "p2p"
+        return _all_agree(same)
 
     @property
     def composite(self):
-        """The exchange step in use (a refused reduce-scatter falls back to the all-reduce)."""
+        """The exchange step in use."""
         return self.slots[0][0].composite
 
     def step(self, camera=None, sun=None):
@@ -161,7 +289,20 @@ class SortLastPipeline:
     def renderers(self):
         return [f.r for f, _ in self.slots]
 
+    def time_composite(self):
+        for f, _ in self.slots:
+            f.time_composite()
+
+    def composite_ms(self):
+        parts = [f.composite_ms() for f, _ in self.slots]
+        parts = [p for p in parts if p]
+        if not parts:
+            return None
+        return sum(p[0] for p in parts) / len(parts), sum(p[1] for p in parts) / len(parts)
+
     def close(self):
         torch.cuda.synchronize()
+        for f, _ in self.slots:
+            f.close()
         for f, _ in self.slots:
             f.r.close()

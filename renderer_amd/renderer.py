@@ -22,6 +22,7 @@ ABI_SYMBOLS = [
     "rdr_get_stats", "rdr_build_ubo", "rdr_get_ubo", "rdr_destroy", "rdr_last_error",
     "rdr_bake_brdf_lut", "rdr_bake_env_map", "rdr_mesh_build", "rdr_mesh_result", "rdr_mesh_free", "rdr_decode_bc",
     "rdr_decode_bc_noalloc", "rdr_frame_status",
+    "rdr_composite_export", "rdr_composite_connect", "rdr_composite_exchange", "rdr_composite_gather", "rdr_composite_disconnect",
 ]
 
 _LIB = None
@@ -63,6 +64,11 @@ def load_library():
     L.rdr_read_color.argtypes = [vp, vp]
     L.rdr_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
     L.rdr_frame_status.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.rdr_composite_export.argtypes = [vp, vp]
+    L.rdr_composite_connect.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+    L.rdr_composite_exchange.argtypes = [vp]
+    L.rdr_composite_gather.argtypes = [vp]
+    L.rdr_composite_disconnect.argtypes = [vp]
     L.rdr_build_ubo.argtypes = [C.c_uint32, C.c_uint32, f3, f3, f3, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(abi.Ubo)]
     L.rdr_get_ubo.argtypes = [vp, C.POINTER(abi.Ubo)]
     L.rdr_destroy.argtypes = [vp]
@@ -160,6 +166,30 @@ class Renderer:
 
     def set_shade_rows(self, lo, hi):
         self._check(self._L.rdr_set_shade_rows(self._h, lo, hi))
+
+    # --- peer-to-peer sort-last exchange (one process per GPU) -------------------------
+    COMPOSITE_HANDLE_BYTES = 192
+
+    def composite_export(self):
+        """This renderer's IPC handles (192 bytes) for the other ranks."""
+        buf = C.create_string_buffer(self.COMPOSITE_HANDLE_BYTES)
+        self._check(self._L.rdr_composite_export(self._h, buf))
+        return buf.raw
+
+    def composite_connect(self, rank, world, handles):
+        """``handles``: every rank's ``composite_export()`` in rank order."""
+        assert len(handles) == world and all(len(h) == self.COMPOSITE_HANDLE_BYTES for h in handles)
+        blob = C.create_string_buffer(b"".join(handles), world * self.COMPOSITE_HANDLE_BYTES)
+        self._check(self._L.rdr_composite_connect(self._h, rank, world, blob))
+
+    def composite_exchange(self):
+        self._check(self._L.rdr_composite_exchange(self._h))
+
+    def composite_gather(self):
+        self._check(self._L.rdr_composite_gather(self._h))
+
+    def composite_disconnect(self):
+        self._check(self._L.rdr_composite_disconnect(self._h))
 
     def set_stream(self, stream_handle):
         self._check(self._L.rdr_set_stream(self._h, C.c_void_p(stream_handle)))

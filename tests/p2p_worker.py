@@ -1,0 +1,85 @@
+"""One rank of the peer-to-peer sort-last test (tests/test_gpu_p2p.py): ``p2p_worker.py rank world dir``.
+Ranks are separate processes (they may share one GPU); handles travel through files in ``dir``."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from renderer_amd import Renderer, RendererConfig, synth  # noqa: E402
+from renderer_amd.distributed import instance_range, row_range  # noqa: E402
+from renderer_amd.scene import Camera  # noqa: E402
+
+W, H = 256, 144
+
+
+def publish(path, data):
+    with open(path + ".tmp", "wb") as f:
+        f.write(data)
+    os.rename(path + ".tmp", path)
+
+
+def wait_for(paths, seconds=60.0):
+    t0 = time.time()
+    while not all(os.path.exists(p) for p in paths):
+        if time.time() - t0 > seconds:
+            raise SystemExit(f"timed out waiting for {[p for p in paths if not os.path.exists(p)]}")
+        time.sleep(0.01)
+
+
+def main():
+    rank, world, d = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    device = int(os.environ.get("P2P_DEVICE", "0"))
+    scene = synth.make_field(60, 3, lods=1, alpha_fraction=0.3, with_env=True, prepared=True)
+    conf = RendererConfig(cull_enabled=False)
+    r = Renderer(W, H, conf, device=device)
+    r.set_scene(scene)
+    r.set_partition(*instance_range(scene.meshlet_visibility_count, rank, world))
+    lo, hi = row_range(H, rank, world)
+    r.set_shade_rows(lo, hi)
+    publish(os.path.join(d, f"handle_{rank}.bin"), r.composite_export())
+    names = [os.path.join(d, f"handle_{k}.bin") for k in range(world)]
+    wait_for(names)
+    r.composite_connect(rank, world, [open(n, "rb").read() for n in names])
+
+    whole = Renderer(W, H, conf, device=device)  # the single-GPU answer, in this process
+    whole.set_scene(scene)
+    base = scene.camera
+    cams = [base, Camera(tuple(np.add(base.position, (3.0, 1.0, -2.0))), base.direction),
+            Camera(tuple(np.add(base.position, (-4.0, 2.0, 5.0))), tuple(np.add(base.direction, (0.1, 0.05, 0.0))))]
+    frames = []
+    for cam in cams:  # frames back to back, no host synchronisation inside a frame
+        r.render_visbuffer(cam)
+        r.composite_exchange()
+        r.shade()
+        r.composite_gather()
+        r.sync()
+        frames.append((r.read_visbuffer_u64().copy(), r.read_color().copy()))
+        # every rank must have read this frame before any rank renders over its buffers: the exchange orders the
+        # device side by itself, this barrier is only for the host readbacks above
+        publish(os.path.join(d, f"read_{len(frames)}_{rank}"), b"1")
+        wait_for([os.path.join(d, f"read_{len(frames)}_{k}") for k in range(world)])
+    ok = True
+    for k, cam in enumerate(cams):
+        whole.render(cam)
+        vis, color = whole.read_visbuffer_u64(), whole.read_color()
+        gv, gc = frames[k]
+        if not np.array_equal(gv[lo:hi], vis[lo:hi]):
+            print(f"rank {rank} frame {k}: {int((gv[lo:hi] != vis[lo:hi]).sum())} composited keys differ", flush=True)
+            ok = False
+        if not np.array_equal(gc, color):
+            print(f"rank {rank} frame {k}: {int((gc != color).any(axis=2).sum())} pixels of the gathered image differ", flush=True)
+            ok = False
+    publish(os.path.join(d, f"done_{rank}"), b"1")
+    wait_for([os.path.join(d, f"done_{k}") for k in range(world)])
+    r.composite_disconnect()
+    r.close()
+    whole.close()
+    print(f"rank {rank}: {'ok' if ok else 'MISMATCH'}", flush=True)
+    raise SystemExit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
