@@ -17,6 +17,10 @@ elif scene_name == "lodfield":  # the field with LOD selection on: coarse levels
 elif scene_name == "alphafield":  # half of the draws alpha-masked with a checkerboard albedo
     scene = synth.make_field(1250, 5, lods=1, alpha_fraction=0.5, with_env=True, prepared=True)
     conf = RendererConfig(lod_enabled=False, cull_enabled=False, collect_stats=True, time_kernels=True)
+elif scene_name == "fieldxl":  # 50 000 instances = 1.02 G triangles at 7680 x 4320
+    w, h = 7680, 4320
+    scene = synth.make_field(50000, 5, lods=1, with_env=True, prepared=True)
+    conf = RendererConfig(lod_enabled=False, cull_enabled=False, collect_stats=True, time_kernels=True)
 else:
     scene = synth.make_atrium(columns=10, spheres=60, sphere_subdiv=5)
     conf = RendererConfig(cull_enabled=os.environ.get("RDR_OCCLUSION", "0") != "0", collect_stats=True, time_kernels=True)
@@ -25,4 +29,6 @@ r.set_scene(scene)
 for _ in range(frames):
     r.render()
 r.sync()
-print(r.stats())
+st = r.stats()
+print(st)
+print("frame_ms (sum of kernel times)", sum(st["kernel_ms"].values()), "frame status", r.frame_status())

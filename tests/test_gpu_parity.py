@@ -306,6 +306,81 @@ def test_full_size_properties():
     assert np.array_equal(acc, full)
 
 
+def _valid_keys(sc, g, cov):
+    xy = g.read_visbuffer()
+    draw, meshlet, tri = xy[..., 1][cov], xy[..., 0][cov] >> 8, xy[..., 0][cov] & 0xFF
+    assert draw.max() < len(sc.mesh_draws) and meshlet.max() < len(sc.meshlets)
+    assert (tri < sc.meshlets["triangle_count"][meshlet]).all()
+
+
+def test_field_xl_8k_properties():
+    """The largest configuration of the measurement plan: 50 000 instances (1.02 G triangles submitted) at
+    7680 x 4320 on one GPU.  No list overflows, every key decodes to a valid triangle, shading covers exactly
+    the keyed pixels, two sort-last partitions min-compose to the full frame, a second frame repeats the first."""
+    sc = synth.make_field(50000, 5, lods=1, with_env=True, prepared=True)
+    w, h = 7680, 4320
+    g = Renderer(w, h, RendererConfig(cull_enabled=False))
+    g.set_scene(sc)
+    g.render()
+    assert g.frame_status() == 0
+    full = g.read_visbuffer_u64().copy()
+    st = g.stats()
+    tris = int(sc.meshlets["triangle_count"][:int(sc.meshes[0]["lods"][0]["meshlet_count"])].sum())
+    assert tris == 20480 and sc.triangle_count() == 50000 * tris
+    assert st["triangles_submitted"] == st["draws_visible"] * tris and 0 < st["draws_visible"] <= 50000  # the far test drops the rest
+    cov = covered(full)
+    assert st["pixels_covered"] == int(cov.sum()) > w * h // 4
+    _valid_keys(sc, g, cov)
+    col = g.read_color()
+    assert (col[..., 3][cov] == 255).all() and (col[~cov] == 0).all()
+    del col
+    g.render()
+    assert np.array_equal(g.read_visbuffer_u64(), full)
+    n = sc.meshlet_visibility_count
+    acc = np.full_like(full, abi.VIS_CLEAR)
+    for k in range(2):
+        g.set_partition(n * k // 2, n * (k + 1) // 2)
+        g.render_visbuffer()
+        assert g.frame_status() == 0
+        acc = np.minimum(acc, g.read_visbuffer_u64())
+    assert np.array_equal(acc, full)
+    g.close()
+
+
+def test_atrium_4k_properties():
+    """The interior scene (textured, every pixel covered, tile path) at the 4K target of the single-GPU
+    configurations: complete frame, valid keys, deterministic, partitions min-compose, occlusion culling neutral."""
+    sc = synth.make_atrium(columns=10, spheres=60, sphere_subdiv=5)
+    w, h = 3840, 2160
+    g = Renderer(w, h, RendererConfig(cull_enabled=False, skybox=True))
+    g.set_scene(sc)
+    g.render()
+    assert g.frame_status() == 0
+    full = g.read_visbuffer_u64().copy()
+    col = g.read_color().copy()
+    st = g.stats()
+    assert st["bin_entries"] > 0 and st["pixels_covered"] == w * h == int(covered(full).sum())
+    _valid_keys(sc, g, covered(full))
+    assert (col[..., 3] == 255).all()
+    g.render()
+    assert np.array_equal(g.read_visbuffer_u64(), full) and np.array_equal(g.read_color(), col)
+    n = sc.meshlet_visibility_count
+    acc = np.full_like(full, abi.VIS_CLEAR)
+    for k in range(4):
+        g.set_partition(n * k // 4, n * (k + 1) // 4)
+        g.render_visbuffer()
+        acc = np.minimum(acc, g.read_visbuffer_u64())
+    assert np.array_equal(acc, full)
+    g.close()
+    c = Renderer(w, h, RendererConfig(cull_enabled=True, skybox=True))
+    c.set_scene(sc)
+    for _ in range(3):
+        c.render()
+    assert c.frame_status() == 0
+    assert np.array_equal(c.read_visbuffer_u64(), full) and np.array_equal(c.read_color(), col)
+    c.close()
+
+
 @pytest.mark.parametrize("lod", [False, True])
 def test_prepared_meshes_with_simplified_lods(oracle, lod):
     """Meshes that went through the library's mesh preparation (cache-ordered meshlets, simplified
