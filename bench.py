@@ -290,8 +290,12 @@ def main():
         else:
             ab_dom, t_dom = ab[dom], kms[dom]
         achieved = ab_dom / (t_dom * 1e-3) / 1e9 if t_dom > 0 else 0.0
+        # HBM traffic and vector-issue figures of the dominant kernel are NOT measured by this run (counters need
+        # rocprofv3 passes of their own): they are read from the committed record of profiles/refresh_r2.sh on the
+        # same workload, and the line says so (traffic_source)
         traffic = None
-        issue = None  # how busy the dominant kernel keeps the vector ALUs (from the same PMC record)
+        issue = None
+        traffic_source = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
@@ -299,6 +303,7 @@ def main():
                 if rec.get("workload") == [args.instances, args.subdivisions, W, H] and world == 1:
                     traffic = rec.get("kernels", {}).get(dom)
                     issue = rec.get("issue", {}).get(dom)
+                    traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of profiles/refresh_r2.sh, committed; not this run)"
             except Exception:
                 traffic = None
         out = {
@@ -331,7 +336,10 @@ def main():
                                                   "triangles_submitted", "triangles_tested", "triangles_rasterised",
                                                   "fragments", "pixels_covered", "vertices_transformed")},
             "roofline": {"kernel": "k_" + dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         # the contract's bound is HBM or MFMA; of the two this path can only meet HBM, but the dominant
+                         # kernel is a divergent tree walk limited by load latency and lane divergence, not by bandwidth
+                         "limited_by": "dependent-load latency and lane divergence (valu_issue: share of vector issue slots used, lanes active)",
                          "algorithmic_bytes": ab_dom, "kernel_ms": t_dom,
                          "frame_algorithmic_bytes": sum(ab.values()),
                          "frame_frac": sum(ab.values()) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
