@@ -125,6 +125,7 @@ extern "C" {
     pub fn rdr_mesh_build(vertices: *const rdr_vertex, vertex_count: u32, indices: *const u32, index_count: u32, max_lods: u32, fast_mode: u32, out: *mut *mut rdr_mesh_builder) -> c_int;
     pub fn rdr_mesh_result(b: *const rdr_mesh_builder, out: *mut rdr_built_mesh) -> c_int;
     pub fn rdr_mesh_free(b: *mut rdr_mesh_builder);
+    pub fn rdr_generate_tangents(vertices: *mut rdr_vertex, vertex_count: u32, indices: *const u32, index_count: u32) -> c_int;
 }
 
 const _: () = {

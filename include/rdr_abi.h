@@ -441,6 +441,13 @@ int rdr_mesh_build(const rdr_vertex* vertices, uint32_t vertex_count, const uint
 int rdr_mesh_result(const rdr_mesh_builder* b, rdr_built_mesh* out);
 void rdr_mesh_free(rdr_mesh_builder* b);
 
+/* Replaces scenery::vertex::generate_tangents (scenery/src/vertex.rs:86-90, called for glTF primitives without a
+ * TANGENT attribute at scenery/src/scene.rs:207), i.e. the mikktspace crate: tangents from the uv parametrisation,
+ * angle-weighted over the triangles that share a vertex, an edge and a uv orientation, w = handedness.  Written into
+ * vertices[indices[k]].t corner by corner in triangle order (a record shared by corners of different groups keeps
+ * the last one, as in the reference).  Host code, no GPU. */
+int rdr_generate_tangents(rdr_vertex* vertices, uint32_t vertex_count, const uint32_t* indices, uint32_t index_count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -165,31 +165,6 @@ def _mul(a, b):
 # ---------------------------------------------------------------------------------------------
 # geometry
 # ---------------------------------------------------------------------------------------------
-def _uv_tangents(pos, nrm, uv, idx):
-    """Per-vertex tangents from the uv gradients of the adjacent triangles (stand-in for
-    mikktspace, scenery/src/vertex.rs:86-90): accumulated, Gram-Schmidt against the normal,
-    w = handedness."""
-    tri = idx.reshape(-1, 3)
-    p0, p1, p2 = pos[tri[:, 0]], pos[tri[:, 1]], pos[tri[:, 2]]
-    w0, w1, w2 = uv[tri[:, 0]], uv[tri[:, 1]], uv[tri[:, 2]]
-    e1, e2 = p1 - p0, p2 - p0
-    d1, d2 = w1 - w0, w2 - w0
-    det = d1[:, 0] * d2[:, 1] - d2[:, 0] * d1[:, 1]
-    r = np.where(np.abs(det) > 1e-20, 1.0 / np.where(det == 0, 1.0, det), 0.0)[:, None]
-    sdir = (e1 * d2[:, 1:2] - e2 * d1[:, 1:2]) * r
-    tdir = (e2 * d1[:, 0:1] - e1 * d2[:, 0:1]) * r
-    tan = np.zeros_like(pos)
-    bit = np.zeros_like(pos)
-    for k in range(3):
-        np.add.at(tan, tri[:, k], sdir)
-        np.add.at(bit, tri[:, k], tdir)
-    t = tan - nrm * (nrm * tan).sum(1, keepdims=True)
-    ln = np.linalg.norm(t, axis=1, keepdims=True)
-    t = np.where(ln > 1e-20, t / np.where(ln == 0, 1.0, ln), np.array([[1.0, 0.0, 0.0]]))
-    w = np.where((np.cross(nrm, t) * bit).sum(1) < 0.0, -1.0, 1.0)
-    return np.concatenate([t, w[:, None]], 1).astype(np.float32)
-
-
 def _primitive_vertices(doc, buffers, prim):
     if prim.get("mode", 4) != 4:
         raise ValueError("only Triangles are supported")
@@ -212,8 +187,9 @@ def _primitive_vertices(doc, buffers, prim):
         v["t"] = _accessor(doc, buffers, at["TANGENT"]).astype(np.float32)[:n]
     else:
         v["t"] = (1.0, 0.0, 0.0, 1.0)
-        if len(idx):
-            v["t"] = _uv_tangents(pos.astype(np.float64), v["n"][:, :3].astype(np.float64), v["uv"][:, :2].astype(np.float64), idx)
+        if len(idx):  # generate_tangents (scenery/src/scene.rs:207)
+            from .meshprep import generate_tangents
+            generate_tangents(v, idx)
     return v, idx
 
 

@@ -55,3 +55,14 @@ def build_mesh(vertices, indices, max_lods=8, fast_mode=False):
                          view(r.meshlets, r.meshlet_count, abi.MESHLET), mesh)
     finally:
         L.rdr_mesh_free(handle)
+
+
+def generate_tangents(vertices, indices):
+    """``scenery::vertex::generate_tangents`` (scenery/src/vertex.rs:86-90, the mikktspace crate): fills the ``t``
+    field of ``vertices`` (abi.VERTEX, modified in place) from positions, normals and uv0 over the triangle list."""
+    L = load_library()
+    assert vertices.dtype == abi.VERTEX and vertices.flags["C_CONTIGUOUS"]
+    i = np.ascontiguousarray(indices, np.uint32).reshape(-1)
+    if L.rdr_generate_tangents(vertices.ctypes.data_as(C.c_void_p), len(vertices), i.ctypes.data_as(C.c_void_p), len(i)):
+        raise RendererError(L.rdr_last_error().decode())
+    return vertices

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "rdr_get_stats", "rdr_build_ubo", "rdr_get_ubo", "rdr_destroy", "rdr_last_error",
     "rdr_bake_brdf_lut", "rdr_bake_env_map", "rdr_mesh_build", "rdr_mesh_result", "rdr_mesh_free", "rdr_decode_bc",
     "rdr_decode_bc_noalloc", "rdr_frame_status",
-    "rdr_composite_export", "rdr_composite_connect", "rdr_composite_exchange", "rdr_composite_gather", "rdr_composite_disconnect",
+    "rdr_composite_export", "rdr_composite_connect", "rdr_composite_exchange", "rdr_composite_gather", "rdr_composite_disconnect", "rdr_generate_tangents",
 ]
 
 _LIB = None
@@ -78,6 +78,7 @@ def load_library():
     L.rdr_mesh_result.argtypes = [vp, C.POINTER(abi.BuiltMesh)]
     L.rdr_mesh_free.argtypes = [vp]
     L.rdr_mesh_free.restype = None
+    L.rdr_generate_tangents.argtypes = [vp, C.c_uint32, vp, C.c_uint32]
     L.rdr_decode_bc.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp]
     L.rdr_decode_bc_noalloc.argtypes = L.rdr_decode_bc.argtypes
     _LIB = L

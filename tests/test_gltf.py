@@ -165,3 +165,36 @@ def test_embedded_image_is_skipped_and_the_scene_still_renders(oracle, tmp_path)
     from renderer_amd import scene_bin
     scene_bin.save_scene_bin(sc, tmp_path / "embedded.bin")
     assert scene_bin.load_scene_bin(tmp_path / "embedded.bin").images == [None]
+
+
+@pytest.mark.gpu
+def test_gltf_without_tangents_renders_on_the_gpu_like_the_oracle(oracle, tmp_path):
+    """A glTF whose primitives carry no TANGENT attribute gets its tangents from the library
+    (rdr_generate_tangents, the reference's generate_tangents at scenery/src/scene.rs:207); the loaded scene then
+    renders through the HIP path to the oracle's keys and, within tolerance, its colours (normal-mapped materials)."""
+    from renderer_amd import Renderer
+    sc = synth.make_atrium()
+    save_gltf(sc, tmp_path / "atrium.gltf")
+    doc = json.load(open(tmp_path / "atrium.gltf"))
+    stripped = 0
+    for m in doc["meshes"]:
+        for p in m["primitives"]:
+            stripped += p["attributes"].pop("TANGENT", None) is not None
+    assert stripped > 0
+    json.dump(doc, open(tmp_path / "atrium.gltf", "w"))
+    back = load_gltf(tmp_path / "atrium.gltf", env=sc.env)
+    back.camera, back.sun_direction = sc.camera, sc.sun_direction
+    t = back.vertices["t"]
+    assert np.abs(np.linalg.norm(t[:, :3], axis=1) - 1.0).max() < 1e-3 and set(np.unique(t[:, 3])) <= {-1.0, 1.0}
+    w, h = 240, 135
+    conf = RendererConfig(cull_enabled=False, skybox=True)
+    o = oracle.OracleRenderer(w, h, conf)
+    o.set_scene(back)
+    ovis = o.render_visbuffer()
+    g = Renderer(w, h, conf)
+    g.set_scene(back)
+    g.render()
+    assert np.array_equal(g.read_visbuffer_u64(), ovis)
+    err = np.abs(g.read_color().astype(int) - o.shade().astype(int))
+    assert err.max() <= 2 and psnr(g.read_color(), o.shade()) >= 40
+    g.close()
