@@ -10,8 +10,9 @@ from renderer_amd import Renderer, RendererConfig
 from renderer_amd.scene import Camera
 from test_gpu_random import soup
 
+SCALE = int(os.environ.get("SWEEP_SCALE", "1"))  # more seeds of every part
 bad = 0
-for seed in (range(100, 160) if os.environ.get("SWEEP_PART", "all") in ("all", "soups") else ()):
+for seed in (range(100, 100 + 60 * SCALE) if os.environ.get("SWEEP_PART", "all") in ("all", "soups") else ()):
     rng = np.random.default_rng(seed)
     w, h = int(rng.integers(1, 700)), int(rng.integers(1, 500))
     masked = bool(rng.integers(0, 2))
@@ -41,7 +42,7 @@ print("done, mismatching frames:", bad)
 # second part: instanced fields (prepared meshlets, simplified LOD chains, alpha-masked draws) from random cameras
 from renderer_amd import synth
 bad = 0
-for seed in (range(200, 230) if os.environ.get("SWEEP_PART", "all") in ("all", "fields") else ()):
+for seed in ((range(20000, 20000 + 30 * SCALE) if SCALE > 1 else range(200, 230)) if os.environ.get("SWEEP_PART", "all") in ("all", "fields") else ()):
     rng = np.random.default_rng(seed)
     w, h = int(rng.integers(64, 900)), int(rng.integers(64, 600))
     subdiv = int(rng.integers(1, 4))
@@ -73,7 +74,7 @@ print("fields done, mismatching frames:", bad)
 # third part: sort-last partitions of random scenes, composited with a 64-bit minimum on the host, against the
 # unpartitioned frame of the same renderer (bit for bit)
 bad = 0
-for seed in (range(300, 330) if os.environ.get("SWEEP_PART", "all") in ("all", "partitions") else ()):
+for seed in ((range(30000, 30000 + 30 * SCALE) if SCALE > 1 else range(300, 330)) if os.environ.get("SWEEP_PART", "all") in ("all", "partitions") else ()):
     rng = np.random.default_rng(seed)
     w, h = int(rng.integers(32, 700)), int(rng.integers(32, 500))
     if seed % 2:
