@@ -79,6 +79,7 @@ pub const RDR_FRAME_MID_OVERFLOW: u32 = 8;
 pub const RDR_FRAME_FRAG_OVERFLOW: u32 = 16;
 pub const RDR_FRAME_LIST_OVERFLOW: u32 = 32;
 pub const RDR_FRAME_SHADOW_STACK: u32 = 64;
+pub const RDR_FRAME_PEER_TIMEOUT: u32 = 128;
 
 pub const RDR_COMPOSITE_MAX_RANKS: usize = 16;
 #[repr(C)] #[derive(Clone, Copy)] pub struct rdr_composite_handle { pub vis: [u8; 64], pub color: [u8; 64], pub ctrl: [u8; 64] }

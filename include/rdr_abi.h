@@ -316,6 +316,7 @@ int rdr_render(rdr_renderer* r, const float cam_pos[3], const float cam_dir[3],
 #define RDR_FRAME_FRAG_OVERFLOW 16u    /* alpha-tested fragment queue */
 #define RDR_FRAME_LIST_OVERFLOW 32u    /* cull command / visible meshlet lists */
 #define RDR_FRAME_SHADOW_STACK 64u     /* a shadow ray's traversal stack overflowed without a hit: its pixel may be lit wrongly */
+#define RDR_FRAME_PEER_TIMEOUT 128u    /* sort-last exchange: a peer rank did not arrive within 5 s (rdr_composite_*) */
 int rdr_frame_status(rdr_renderer* r, uint32_t* flags);
 
 /* The two halves of rdr_render, for sort-last rendering: geometry into the

@@ -76,7 +76,7 @@ NO_TEXTURE = 0xFFFFFFFF
 FORMAT_RGBA8_UNORM, FORMAT_RGBA8_SRGB, FORMAT_RGBA32F = 0, 1, 2
 # rdr_frame_status flags
 (FRAME_DEFERRED_OVERFLOW, FRAME_SETUP_OVERFLOW, FRAME_BIN_OVERFLOW, FRAME_MID_OVERFLOW, FRAME_FRAG_OVERFLOW,
- FRAME_LIST_OVERFLOW, FRAME_SHADOW_STACK) = 1, 2, 4, 8, 16, 32, 64
+ FRAME_LIST_OVERFLOW, FRAME_SHADOW_STACK, FRAME_PEER_TIMEOUT) = 1, 2, 4, 8, 16, 32, 64, 128
 FORMAT_BC1, FORMAT_BC2, FORMAT_BC3, FORMAT_BC4 = 3, 4, 5, 6  # block-compressed, decoded to RGBA8_UNORM at upload
 VIS_CLEAR = 0x7FFFFFFFFFFFFFFF
 

@@ -858,7 +858,8 @@ int rdr_frame_status(rdr_renderer* r, uint32_t* flags) {
     RDR_HIP(hipStreamSynchronize(r->stream));
     r->seen_status[0] = r->status_host[0];
     r->seen_status[1] = r->status_host[1];
-    *flags = (r->seen_status[0] | r->seen_status[1]) & 0xFFu;
+    *flags = (r->seen_status[0] | r->seen_status[1]) & 0x7Fu;
+    if (rdr_composite_timed_out(r->composite)) *flags |= RDR_FRAME_PEER_TIMEOUT;
     return 0;
 }
 

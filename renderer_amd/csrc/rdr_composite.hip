@@ -156,7 +156,7 @@ int rdr_composite_export_handles(rdr_composite_state* c, void* vis, void* color,
 int rdr_composite_open(rdr_composite_state* c, uint32_t rank, uint32_t world, const rdr_composite_handle* handles, void* vis, void* color) {
     RDR_CHECK(world >= 1 && world <= RDR_COMPOSITE_MAX_RANKS && rank < world, "rdr_composite_connect: rank / world out of range (at most 16 ranks)");
     RDR_CHECK(!c->connected, "rdr_composite_connect: already connected");
-    c->rank = rank; c->world = world; c->frame = 0;
+    c->rank = rank; c->world = world; // the frame number keeps counting across connections: phases only ever grow
     for (uint32_t p = 0; p < world; ++p) {
         if (p == rank) {
             c->peers.vis[p] = static_cast<unsigned long long*>(vis);
@@ -179,6 +179,8 @@ int rdr_composite_open(rdr_composite_state* c, uint32_t rank, uint32_t world, co
     c->connected = true;
     return 0;
 }
+
+bool rdr_composite_timed_out(const rdr_composite_state* c) { return c && *c->timed_out != 0; }
 
 int rdr_composite_check(rdr_composite_state* c, const char* who) {
     if (*c->timed_out) {

@@ -390,6 +390,7 @@ void rdr_composite_destroy(rdr_composite_state* c);
 int rdr_composite_export_handles(rdr_composite_state* c, void* vis, void* color, rdr_composite_handle* out);
 int rdr_composite_open(rdr_composite_state* c, uint32_t rank, uint32_t world, const rdr_composite_handle* handles, void* vis, void* color);
 int rdr_composite_check(rdr_composite_state* c, const char* who);
+bool rdr_composite_timed_out(const rdr_composite_state* c); // a bounded wait gave up (not cleared by asking)
 int rdr_composite_launch_exchange(rdr_composite_state* c, uint32_t width, uint32_t row_lo, uint32_t row_hi, hipStream_t stream);
 int rdr_composite_launch_gather(rdr_composite_state* c, uint32_t width, uint32_t row_lo, uint32_t row_hi, hipStream_t stream);
 size_t rdr_bc_level_bytes(uint32_t format, uint32_t width, uint32_t height);

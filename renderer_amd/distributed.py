@@ -256,14 +256,22 @@ class SortLastPipeline:
 
     def _p2p_matches_collective(self, height, rank, world):
         """One frame composited both ways on slot 0: the keys of this rank's rows and the gathered image must be
-        identical on every rank."""
+        identical on every rank.  The peer-to-peer frame contains no collective, so a rank on which it fails (an
+        exception, a peer that never arrives) still meets the others in the agreement that follows it."""
         f, stream = self.slots[0]
         lo, hi = row_range(height, rank, world)
+        keys = image = None
         with torch.cuda.stream(stream):
-            f.step()
-            torch.cuda.synchronize()
-            keys = f.vis.view(height, -1)[lo:hi].clone()
-            image = f.color.clone()
+            try:
+                f.step()
+                torch.cuda.synchronize()
+                ok = f.r.frame_status() == 0
+                keys = f.vis.view(height, -1)[lo:hi].clone()
+                image = f.color.clone()
+            except Exception:
+                ok = False
+            if not _all_agree(ok):
+                return False
             f.composite = "all_reduce"
             f.step()
             torch.cuda.synchronize()

@@ -44,6 +44,35 @@ def main():
     wait_for(names)
     r.composite_connect(rank, world, [open(n, "rb").read() for n in names])
 
+    if os.environ.get("P2P_MODE") == "timeout":
+        # rank 0 runs a frame, rank 1 never does: rank 0's wait must give up by itself and say so
+        from renderer_amd import RendererError, abi
+        if rank == 0:
+            t0 = time.time()
+            r.render_visbuffer()
+            r.composite_exchange()
+            flags = r.frame_status()  # waits for the stream: returns once the bounded wait has given up
+            waited = time.time() - t0
+            ok = bool(flags & abi.FRAME_PEER_TIMEOUT) and 3.0 < waited < 30.0
+            try:
+                r.composite_exchange()
+                ok = False
+            except RendererError as e:
+                ok = ok and "peer rank" in str(e)
+            print(f"rank 0: waited {waited:.1f} s, flags {flags:#x}, {'ok' if ok else 'MISMATCH'}", flush=True)
+            publish(os.path.join(d, "timeout_seen"), b"1")
+        else:
+            wait_for([os.path.join(d, "timeout_seen")], 90.0)
+            ok = True
+        publish(os.path.join(d, f"done_{rank}"), b"1")
+        wait_for([os.path.join(d, f"done_{k}") for k in range(world)])
+        try:
+            r.composite_disconnect()
+        except RendererError:
+            pass
+        r.close()
+        raise SystemExit(0 if ok else 1)
+
     whole = Renderer(W, H, conf, device=device)  # the single-GPU answer, in this process
     whole.set_scene(scene)
     base = scene.camera

@@ -11,9 +11,8 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_ranks_sharing_one_gpu_composite_to_the_single_gpu_frame(tmp_path, world):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _run_ranks(tmp_path, world, **extra_env):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "p2p_worker.py"), str(k), str(world), str(tmp_path)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for k in range(world)]
     outs = []
@@ -26,3 +25,16 @@ def test_ranks_sharing_one_gpu_composite_to_the_single_gpu_frame(tmp_path, world
             raise
         outs.append(out)
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    return outs
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_sharing_one_gpu_composite_to_the_single_gpu_frame(tmp_path, world):
+    _run_ranks(tmp_path, world)
+
+
+def test_a_peer_that_never_arrives_is_an_error_not_a_hang(tmp_path):
+    """The waits between ranks are bounded: rank 1 connects but renders nothing; rank 0's exchange gives up after
+    about five seconds, reports RDR_FRAME_PEER_TIMEOUT and fails its next exchange call."""
+    outs = _run_ranks(tmp_path, 2, P2P_MODE="timeout")
+    assert "rank 0: waited" in outs[0]
