@@ -66,6 +66,7 @@ struct rdr_renderer {
     uint64_t frames_started = 0; // frames since the last rdr_get_stats
     int cur_slot = 0;
     bool frame_rendered = false, shaded = false;
+    bool timing_this_frame = false;
 
     // frame resources
     DeviceBuffer<unsigned long long> vis;
@@ -353,7 +354,14 @@ FrameView make_frame_view(rdr_renderer* r) {
     fv.commands = r->commands.ptr;
     fv.visible = r->visible.ptr;
     fv.deferred = r->deferred.ptr;
-    fv.counters = r->counters.ptr;
+    {
+        const uint32_t set = r->frame_seq & 1u;
+        const size_t n_tiles = r->tile_count.count / 2;
+        fv.counters = r->counters.ptr + set;
+        fv.counters_next = r->counters.ptr + (set ^ 1u);
+        fv.tile_count = r->tile_count.ptr + set * n_tiles;
+        fv.tile_count_next = r->tile_count.ptr + (set ^ 1u) * n_tiles;
+    }
     fv.width = r->width; fv.height = r->height;
     fv.part_lo = r->part_lo; fv.part_hi = r->part_hi;
     fv.row_lo = std::min(r->row_lo, r->height);
@@ -371,7 +379,6 @@ FrameView make_frame_view(rdr_renderer* r) {
     fv.deferred_capacity = std::min(fv.deferred_capacity, r->debug_deferred_capacity);
     fv.setup = r->setup.ptr;
     fv.setup_mask = r->setup_mask.ptr;
-    fv.tile_count = r->tile_count.ptr;
     fv.tile_offset = r->tile_offset.ptr;
     fv.tile_cursor = r->tile_cursor.ptr;
     fv.tile_list = r->tile_list.ptr;
@@ -430,7 +437,7 @@ FrameView make_frame_view(rdr_renderer* r) {
 
 int fetch_counters(rdr_renderer* r, FrameCounters* out) {
     RDR_HIP(hipStreamSynchronize(r->stream));
-    RDR_HIP(hipMemcpy(out, r->counters.ptr, sizeof(FrameCounters), hipMemcpyDeviceToHost));
+    RDR_HIP(hipMemcpy(out, r->counters.ptr + (r->frame_seq & 1u), sizeof(FrameCounters), hipMemcpyDeviceToHost));
     r->seen_status[0] = r->status_host[0]; // this call reports the frame itself
     r->seen_status[1] = r->status_host[1];
     RDR_CHECK(out->deferred_overflow == 0 && out->setup_overflow == 0 && out->bin_overflow == 0 && out->mid_overflow == 0 && out->frag_overflow == 0,
@@ -517,16 +524,16 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
         for (auto& e : r->ring) RDR_HIP(hipEventCreate(&e));
     }
     const size_t npx = (size_t)width * height;
-    if (r->vis.alloc(npx) || r->color.alloc(npx * 4) || r->counters.alloc(1) || r->shadow.alloc(npx) ||
+    if (r->vis.alloc(npx) || r->color.alloc(npx * 4) || r->counters.alloc(2) || r->shadow.alloc(npx) ||
         r->pixel_list.alloc(npx)) return 1;
     // depth pyramid: W/2 x H/2 and its mips, a little over a third of a pixel count
     if (r->pyramid.alloc(npx / 2 + width + height + 64)) return 1; // sum over levels <= W*H/3 + W + H + levels
     {
         const size_t n_tiles = (size_t)((width + 63) / 64) * ((height + 63) / 64);
-        if (r->tile_count.alloc(n_tiles) || r->tile_offset.alloc(n_tiles) || r->tile_cursor.alloc(n_tiles)) return 1;
-        RDR_HIP(hipMemset(r->tile_count.ptr, 0, n_tiles * 4));
+        if (r->tile_count.alloc(2 * n_tiles) || r->tile_offset.alloc(n_tiles) || r->tile_cursor.alloc(n_tiles)) return 1;
+        RDR_HIP(hipMemset(r->tile_count.ptr, 0, 2 * n_tiles * 4));
     }
-    RDR_HIP(hipMemset(r->counters.ptr, 0, sizeof(FrameCounters)));
+    RDR_HIP(hipMemset(r->counters.ptr, 0, 2 * sizeof(FrameCounters)));
     {
         void* host = nullptr;
         void* dev = nullptr;
@@ -655,7 +662,7 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
             r->mid.alloc(n_mid) || r->mid_mask.alloc(n_mid)) return 1;
         if (r->bin_entries.alloc(std::max<size_t>(n_def * 4, (size_t)1 << 22))) return 1;
         // jobs of the tile rasteriser: at most one partly filled job per tile plus the full ones
-        if (r->tile_list.alloc(((size_t)r->tile_count.count + r->bin_entries.count / kTileJob + 1) * 4)) return 1; // x parts per tile
+        if (r->tile_list.alloc(((size_t)r->tile_count.count / 2 + r->bin_entries.count / kTileJob + 1) * 4)) return 1; // x parts per tile
         // small alpha-tested triangles and their covered pixels (at most 16 each): every LOD-0 triangle of the
         // alpha-tested draws, capped like the lists above
         const size_t n_frag = (size_t)std::min<uint64_t>(std::max<uint64_t>(32 * segment_worst(r->masked_meshlets, r->resident.raster_mask), 1u << 12), 1u << 22);
@@ -780,7 +787,9 @@ int rdr_render_visbuffer(rdr_renderer* r, const float cam_pos[3], const float ca
     build_ubo(r->width, r->height, cam_pos, cam_dir, sun_dir, r->sv.draw_count, r->cfg.lod_enabled, r->cfg.cull_enabled, &r->ubo);
     const FrameView fv = make_frame_view(r);
     hipEvent_t* ev = nullptr;
-    if (r->cfg.time_kernels) {
+    // time_kernels = n: every n-th frame is bracketed (the brackets themselves cost about 3 us each, 33 us per frame)
+    r->timing_this_frame = r->cfg.time_kernels && (r->frame_seq % r->cfg.time_kernels) == 0;
+    if (r->timing_this_frame) {
         r->cur_slot = (int)(r->frames_started % rdr_renderer::kRing);
         r->frames_started++;
         r->slot_geometry[r->cur_slot] = true;
@@ -800,7 +809,7 @@ int rdr_shade(rdr_renderer* r) {
     if (check_finished_frames(r, "rdr_shade")) return 1;
     FrameView fv = make_frame_view(r);
     fv.list_heads_zero = r->shaded ? 0u : 1u; // first shading pass over this visibility buffer
-    hipEvent_t* ev = r->cfg.time_kernels ? r->ring.data() + (size_t)r->cur_slot * rdr_renderer::kEvents : nullptr;
+    hipEvent_t* ev = r->timing_this_frame ? r->ring.data() + (size_t)r->cur_slot * rdr_renderer::kEvents : nullptr;
     if (rdr_launch_shade(r->sv, fv, r->stream, ev)) return 1;
     r->shaded = true;
     if (ev) r->slot_shade[r->cur_slot] = true;

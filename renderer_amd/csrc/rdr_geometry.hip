@@ -1221,6 +1221,55 @@ RDR_DEV void bin_visit(const FrameView& fv, const SetupTri& t, uint32_t record, 
     }
 }
 
+// Prefix sum of the per-tile counts -> bin offsets, and the job list of k_tile_raster: a tile's bin is cut
+// into jobs of kTileJob records, so that a tile under many expensive (large, alpha-tested) triangles is
+// worked on by several workgroups instead of setting the kernel's length alone.  Both sums travel in one
+// 64-bit value: entries in the low 40 bits, jobs above.
+template <uint32_t N>
+RDR_DEV void tile_scan(const FrameView& fv, unsigned long long* partial /* N entries of LDS */) {
+    const uint32_t n_tiles = fv.tiles_x * fv.tiles_y;
+    const uint32_t per = (n_tiles + N - 1u) / N;
+    const uint32_t first = threadIdx.x * per, last = min(first + per, n_tiles);
+    unsigned long long sum = 0;
+    for (uint32_t i = first; i < last; ++i) {
+        const uint32_t c = fv.tile_count[i];
+        sum += (unsigned long long)c + ((unsigned long long)((c + kTileJob - 1u) / kTileJob * kTileParts) << 40);
+    }
+    partial[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < N; o <<= 1) { // inclusive Hillis-Steele scan
+        const unsigned long long v = threadIdx.x >= o ? partial[threadIdx.x - o] : 0ull;
+        __syncthreads();
+        partial[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const unsigned long long before = partial[threadIdx.x] - sum;
+    uint32_t run = (uint32_t)(before & ((1ull << 40) - 1ull)), listed = (uint32_t)(before >> 40);
+    for (uint32_t i = first; i < last; ++i) {
+        const uint32_t c = fv.tile_count[i];
+        fv.tile_offset[i] = run;
+        fv.tile_cursor[i] = 0u;
+        for (uint32_t r = 0; r < c; r += kTileJob)
+            for (uint32_t part = 0; part < kTileParts; ++part, ++listed)
+                if (listed < fv.tile_list_capacity) fv.tile_list[listed] = make_uint2(i, r | part); // kTileJob >= kTileParts: the low bits are free
+        run += c;
+    }
+    if (threadIdx.x == N - 1u) {
+        const unsigned long long total = partial[N - 1u] & ((1ull << 40) - 1ull);
+        fv.counters->bin_total = (uint32_t)min(total, 0xFFFFFFFFull);
+        fv.counters->tile_nonempty = (uint32_t)min(partial[N - 1u] >> 40, (unsigned long long)fv.tile_list_capacity);
+        if (total > fv.bin_capacity) fv.counters->bin_overflow = 1u;
+    }
+}
+
+// The prefix sum runs as a launch of its own between the counting and the filling pass.  Folding it into the tail
+// of the counting pass (last workgroup to finish scans, found by a ticket behind a release fence) was slower: 512
+// fences and tickets and a 256-thread scan took 18 us on a frame with nothing to bin, the two launches 8.6 us.
+__global__ __launch_bounds__(1024) void k_tile_scan(FrameView fv) {
+    __shared__ unsigned long long partial[1024];
+    tile_scan<1024>(fv, partial);
+}
+
 constexpr uint32_t kBinChunk = 4;
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_tile_bin(FrameView fv) {
@@ -1281,47 +1330,6 @@ __global__ __launch_bounds__(256) void k_tile_bin(FrameView fv) {
     }
 }
 
-// Prefix sum of the per-tile counts -> bin offsets, and the job list of k_tile_raster: a tile's bin is cut
-// into jobs of kTileJob records, so that a tile under many expensive (large, alpha-tested) triangles is
-// worked on by several workgroups instead of setting the kernel's length alone.  Both sums travel in one
-// 64-bit value: entries in the low 40 bits, jobs above.
-__global__ __launch_bounds__(1024) void k_tile_scan(FrameView fv) {
-    __shared__ unsigned long long partial[1024];
-    const uint32_t n_tiles = fv.tiles_x * fv.tiles_y;
-    const uint32_t per = (n_tiles + 1023u) / 1024u;
-    const uint32_t first = threadIdx.x * per, last = min(first + per, n_tiles);
-    unsigned long long sum = 0;
-    for (uint32_t i = first; i < last; ++i) {
-        const uint32_t c = fv.tile_count[i];
-        sum += (unsigned long long)c + ((unsigned long long)((c + kTileJob - 1u) / kTileJob * kTileParts) << 40);
-    }
-    partial[threadIdx.x] = sum;
-    __syncthreads();
-    for (uint32_t o = 1; o < 1024; o <<= 1) { // inclusive Hillis-Steele scan
-        const unsigned long long v = threadIdx.x >= o ? partial[threadIdx.x - o] : 0ull;
-        __syncthreads();
-        partial[threadIdx.x] += v;
-        __syncthreads();
-    }
-    const unsigned long long before = partial[threadIdx.x] - sum;
-    uint32_t run = (uint32_t)(before & ((1ull << 40) - 1ull)), listed = (uint32_t)(before >> 40);
-    for (uint32_t i = first; i < last; ++i) {
-        const uint32_t c = fv.tile_count[i];
-        fv.tile_offset[i] = run;
-        fv.tile_cursor[i] = 0u;
-        for (uint32_t r = 0; r < c; r += kTileJob)
-            for (uint32_t part = 0; part < kTileParts; ++part, ++listed)
-                if (listed < fv.tile_list_capacity) fv.tile_list[listed] = make_uint2(i, r | part); // kTileJob >= kTileParts: the low bits are free
-        run += c;
-    }
-    if (threadIdx.x == 1023) {
-        const unsigned long long total = partial[1023] & ((1ull << 40) - 1ull);
-        fv.counters->bin_total = (uint32_t)min(total, 0xFFFFFFFFull);
-        fv.counters->tile_nonempty = (uint32_t)min(partial[1023] >> 40, (unsigned long long)fv.tile_list_capacity);
-        if (total > fv.bin_capacity) fv.counters->bin_overflow = 1u;
-    }
-}
-
 // A workgroup takes jobs: kTileJob records of one tile's bin over one kTilePart x kTilePart piece of the
 // tile, a thread owning B x B pixels of it.  Small jobs in a one-resident-round grid, because what a tile
 // costs is mostly the chain of dependent loads in front of the arithmetic (list -> count / offset -> bin ->
@@ -1338,6 +1346,13 @@ __global__ __launch_bounds__((kTilePart / B) * (kTilePart / B)) void k_tile_rast
     static_assert(kTileJob <= kTileBatch, "a job is staged in one batch");
     uint32_t frags = 0;
     const uint32_t n_listed = min(fv.counters->tile_nonempty, fv.tile_list_capacity);
+    {   // the sets of list heads and tile counts the next frame will use (FrameView::counters_next)
+        const uint32_t n_words = (uint32_t)(sizeof(FrameCounters) / 4u), n_tiles = fv.tiles_x * fv.tiles_y;
+        for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n_words + n_tiles; w += gridDim.x * blockDim.x) {
+            if (w < n_words) reinterpret_cast<uint32_t*>(fv.counters_next)[w] = 0u;
+            else fv.tile_count_next[w - n_words] = 0u;
+        }
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // last kernel of the geometry half: every producer of the lists has finished, so the overflow
         // counters are final; leave the frame's status where the host sees it without a synchronisation
@@ -1668,8 +1683,11 @@ int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t st
     const uint32_t clear_blocks = clear_in_cull ? (n_tiles + 255u) / 256u : (uint32_t)((npx / 2 + 1 + 255) / 256);
     const uint32_t cull_clear_blocks = (uint32_t)((npx / 2 + 1 + 1024u * kClearPerThread - 1) / (1024u * kClearPerThread));
     if (ev) RDR_HIP(hipEventRecord(ev[0], stream));
-    hipLaunchKernelGGL(k_clear, dim3(std::max(clear_blocks, 1u)), dim3(256), 0, stream, fv.vis, clear_in_cull ? (size_t)0 : npx, fv.counters,
-                       fv.tile_count, n_tiles);
+    if (!clear_in_cull) {
+        // a scene without draws: nothing else runs, so the clear is a launch of its own and zeroes both sets of heads
+        hipLaunchKernelGGL(k_clear, dim3(std::max(clear_blocks, 1u)), dim3(256), 0, stream, fv.vis, npx, fv.counters, fv.tile_count, n_tiles);
+        hipLaunchKernelGGL(k_clear, dim3(std::max((n_tiles + 255u) / 256u, 1u)), dim3(256), 0, stream, fv.vis, (size_t)0, fv.counters_next, fv.tile_count_next, n_tiles);
+    }
     if (ev) RDR_HIP(hipEventRecord(ev[1], stream));
     // one pass of the rasterisers over the current work lists
     auto raster_lists = [&](const FrameView& f, hipEvent_t* mid_event) {

@@ -305,6 +305,10 @@ struct FrameView {
     VisibleMeshlet* visible;
     DeferredTriangle* deferred;
     FrameCounters* counters;
+    // The list heads and the per-tile counts exist twice and frames alternate between the sets: a frame's last
+    // geometry kernel zeroes the set the next frame will use, so no frame starts with a launch that only clears.
+    FrameCounters* counters_next;
+    uint32_t* tile_count_next;
     uint32_t width, height;
     uint32_t part_lo, part_hi;
     uint32_t row_lo, row_hi;
