@@ -355,8 +355,14 @@ void* rdr_color_device_ptr(rdr_renderer* r);
 /* Ranks are ordered against each other by phase counters in device      */
 /* memory; a rank whose peer does not arrive within 5 s gets an error    */
 /* from its next call instead of a hang.  Rows must be a partition of    */
-/* the image among the ranks; width x rows of every strip must be a      */
-/* multiple of four pixels.                                               */
+/* the image among the ranks, and every rank has the same width and      */
+/* height.  Both directions move 32x32-pixel tiles and leave out those   */
+/* that cannot matter: keys come only from ranks whose rasterisers       */
+/* touched the tile (a flag per tile, kept while connected), colour      */
+/* tiles go out unless clear now and the frame before (with a skybox     */
+/* every tile goes).  So: render the visibility buffer after connecting, */
+/* and while connected let only the gathers write image rows outside     */
+/* the own strip.                                                         */
 /* ------------------------------------------------------------------ */
 #define RDR_COMPOSITE_MAX_RANKS 16
 typedef struct rdr_composite_handle { /* three hipIpcMemHandle_t: keys, image, control block */

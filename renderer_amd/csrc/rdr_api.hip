@@ -66,6 +66,7 @@ struct rdr_renderer {
     uint64_t frames_started = 0; // frames since the last rdr_get_stats
     int cur_slot = 0;
     bool frame_rendered = false, shaded = false;
+    bool frame_has_tile_flags = false; // the visibility buffer on the device was rendered with FrameView::touched kept
     bool timing_this_frame = false;
 
     // frame resources
@@ -350,6 +351,10 @@ FrameView make_frame_view(rdr_renderer* r) {
     FrameView fv{};
     fv.ubo = r->ubo;
     fv.vis = r->vis.ptr;
+    const bool flags = rdr_composite_connected(r->composite);
+    fv.touched = flags ? reinterpret_cast<uint32_t*>(r->vis.ptr + (size_t)r->width * r->height) : nullptr;
+    fv.touched_x = (r->width + kTouchTile - 1) / kTouchTile;
+    fv.touched_count = rdr_touched_words(r->width, r->height);
     fv.color = r->color.ptr;
     fv.commands = r->commands.ptr;
     fv.visible = r->visible.ptr;
@@ -416,8 +421,8 @@ FrameView make_frame_view(rdr_renderer* r) {
     GridPlan& g = fv.grid;
     g.draw_blocks = std::max(1u, (r->sv.draw_count + 255u) / 256u);
     g.cull_blocks = std::max(1u, std::min((fv.command_capacity + 15u) / 16u, std::max(1u, r->resident.meshlet_cull)));
-    g.raster_blocks = std::max(1u, std::min(fv.visible_capacity, std::max(1u, r->resident.raster)));
-    g.raster_mask_blocks = std::max(1u, std::min(r->masked_meshlets, std::max(1u, r->resident.raster_mask)));
+    g.raster_blocks = std::max(1u, std::min(fv.visible_capacity, std::max(1u, fv.touched ? r->resident.raster_touch : r->resident.raster)));
+    g.raster_mask_blocks = std::max(1u, std::min(r->masked_meshlets, std::max(1u, fv.touched ? r->resident.raster_mask_touch : r->resident.raster_mask)));
     // the tile rasteriser's workgroups take tiles from the list of non-empty ones: one resident round
     g.deferred_blocks = std::max(1u, std::min(fv.tiles_x * fv.tiles_y, r->resident.tile_raster));
     g.mid_blocks = std::max(1u, r->resident.mid_raster);
@@ -524,7 +529,8 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
         for (auto& e : r->ring) RDR_HIP(hipEventCreate(&e));
     }
     const size_t npx = (size_t)width * height;
-    if (r->vis.alloc(npx) || r->color.alloc(npx * 4) || r->counters.alloc(2) || r->shadow.alloc(npx) ||
+    // the sort-last tile flags (FrameView::touched) live behind the keys, in the allocation the peers open
+    if (r->vis.alloc(npx + (rdr_touched_words(width, height) + 1) / 2) || r->color.alloc(npx * 4) || r->counters.alloc(2) || r->shadow.alloc(npx) ||
         r->pixel_list.alloc(npx)) return 1;
     // depth pyramid: W/2 x H/2 and its mips, a little over a third of a pixel count
     if (r->pyramid.alloc(npx / 2 + width + height + 64)) return 1; // sum over levels <= W*H/3 + W + H + levels
@@ -657,7 +663,7 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
         const size_t n_def = (size_t)std::min<uint64_t>(std::max<uint64_t>(tri_total, 1u << 16), 1u << 22);
         // mid queue: k_raster's opaque mid-sized triangles plus the alpha-tested ones k_tile_setup passes on from
         // the deferred list (its 1024 workgroups take deferred triangles a grid apart: n_def / 32 + 32 per segment)
-        const size_t n_mid = (size_t)std::min<uint64_t>(32 * (segment_worst(vis_cap, r->resident.raster) + n_def / 32 + 32), (uint64_t)2 << 22);
+        const size_t n_mid = (size_t)std::min<uint64_t>(32 * (std::max(segment_worst(vis_cap, r->resident.raster), segment_worst(vis_cap, r->resident.raster_touch)) + n_def / 32 + 32), (uint64_t)2 << 22);
         if (r->deferred.alloc(n_def) || r->setup.alloc(n_def + n_def / 2) || r->setup_mask.alloc(n_def + n_def / 2) ||
             r->mid.alloc(n_mid) || r->mid_mask.alloc(n_mid)) return 1;
         if (r->bin_entries.alloc(std::max<size_t>(n_def * 4, (size_t)1 << 22))) return 1;
@@ -665,7 +671,7 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
         if (r->tile_list.alloc(((size_t)r->tile_count.count / 2 + r->bin_entries.count / kTileJob + 1) * 4)) return 1; // x parts per tile
         // small alpha-tested triangles and their covered pixels (at most 16 each): every LOD-0 triangle of the
         // alpha-tested draws, capped like the lists above
-        const size_t n_frag = (size_t)std::min<uint64_t>(std::max<uint64_t>(32 * segment_worst(r->masked_meshlets, r->resident.raster_mask), 1u << 12), 1u << 22);
+        const size_t n_frag = (size_t)std::min<uint64_t>(std::max<uint64_t>(32 * std::max(segment_worst(r->masked_meshlets, r->resident.raster_mask), segment_worst(r->masked_meshlets, r->resident.raster_mask_touch)), 1u << 12), 1u << 22);
         if (r->frag_tri.alloc(n_frag) || r->frag_px.alloc(n_frag * 16)) return 1;
         // zeroed once: a consumer that meets a never-written entry (only possible after an overflow, which is
         // reported as an error) then reads a valid index
@@ -798,6 +804,7 @@ int rdr_render_visbuffer(rdr_renderer* r, const float cam_pos[3], const float ca
     }
     if (rdr_launch_geometry(r->sv, fv, r->stream, ev)) return 1;
     r->frame_rendered = true;
+    r->frame_has_tile_flags = fv.touched != nullptr;
     r->shaded = false;
     return 0;
 }
@@ -832,15 +839,16 @@ int rdr_composite_connect(rdr_renderer* r, uint32_t rank, uint32_t world, const 
     RDR_CHECK(r && handles, "rdr_composite_connect: null argument");
     RDR_CHECK(r->composite, "rdr_composite_connect: call rdr_composite_export first (the peers need this rank's handles too)");
     RDR_HIP(hipSetDevice(r->device));
-    return rdr_composite_open(r->composite, rank, world, handles, r->vis.ptr, r->color.ptr);
+    return rdr_composite_open(r->composite, rank, world, handles, r->vis.ptr, r->color.ptr, r->width, r->height);
 }
 
 int rdr_composite_exchange(rdr_renderer* r) {
     RDR_CHECK(r && r->composite, "rdr_composite_exchange: not connected");
     RDR_CHECK(r->frame_rendered, "rdr_composite_exchange: no visibility buffer rendered yet");
+    RDR_CHECK(r->frame_has_tile_flags, "rdr_composite_exchange: the visibility buffer was rendered before rdr_composite_connect; render it again");
     RDR_HIP(hipSetDevice(r->device));
     if (rdr_composite_check(r->composite, "rdr_composite_exchange")) return 1;
-    return rdr_composite_launch_exchange(r->composite, r->width, std::min(r->row_lo, r->height), std::min(r->row_hi, r->height), r->stream);
+    return rdr_composite_launch_exchange(r->composite, std::min(r->row_lo, r->height), std::min(r->row_hi, r->height), r->stream);
 }
 
 int rdr_composite_gather(rdr_renderer* r) {
@@ -848,7 +856,7 @@ int rdr_composite_gather(rdr_renderer* r) {
     RDR_CHECK(r->shaded, "rdr_composite_gather: nothing shaded yet");
     RDR_HIP(hipSetDevice(r->device));
     if (rdr_composite_check(r->composite, "rdr_composite_gather")) return 1;
-    return rdr_composite_launch_gather(r->composite, r->width, std::min(r->row_lo, r->height), std::min(r->row_hi, r->height), r->stream);
+    return rdr_composite_launch_gather(r->composite, std::min(r->row_lo, r->height), std::min(r->row_hi, r->height), r->cfg.skybox != 0, r->stream);
 }
 
 int rdr_composite_disconnect(rdr_renderer* r) {

@@ -21,6 +21,7 @@
 // wait is bounded (about five seconds of wall clock): a peer that never arrives turns into an error
 // flag, not a hang.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "rdr_internal.h"
@@ -32,6 +33,7 @@ constexpr long long kWaitTicks = 500000000;  // wall_clock64 runs at 100 MHz: 5 
 
 struct PeerTable {
     unsigned long long* vis[RDR_COMPOSITE_MAX_RANKS];
+    uint32_t* touched[RDR_COMPOSITE_MAX_RANKS]; // the tile flags behind each visibility buffer
     uint32_t* color[RDR_COMPOSITE_MAX_RANKS];
     uint32_t* ctrl[RDR_COMPOSITE_MAX_RANKS];
 };
@@ -60,34 +62,115 @@ __global__ void k_wait(const uint32_t* ctrl, uint32_t rank, uint32_t world, uint
     }
 }
 
-// This rank's strip of the composited visibility buffer: minimum over every rank's keys, two keys (16
-// bytes) per lane, all peers' loads in flight together.
-__global__ __launch_bounds__(256) void k_composite_min(PeerTable peers, uint32_t rank, uint32_t world, size_t first_pair, size_t n_pairs) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pairs) return;
-    ulonglong2* mine = reinterpret_cast<ulonglong2*>(peers.vis[rank]) + first_pair + i;
-    ulonglong2 v[RDR_COMPOSITE_MAX_RANKS];
-#pragma unroll
-    for (uint32_t p = 0; p < RDR_COMPOSITE_MAX_RANKS; ++p)
-        if (p < world) v[p] = reinterpret_cast<const ulonglong2*>(peers.vis[p])[first_pair + i];
-    ulonglong2 m = v[0];
-#pragma unroll
-    for (uint32_t p = 1; p < RDR_COMPOSITE_MAX_RANKS; ++p)
-        if (p < world) {
-            m.x = v[p].x < m.x ? v[p].x : m.x;
-            m.y = v[p].y < m.y ? v[p].y : m.y;
-        }
-    *mine = m;
+// The exchange works on tiles of kTouchTile x kTouchTile pixels.  Every rank's rasterisers leave one word per
+// tile behind their visibility buffer (FrameView::touched): non-zero when the tile may hold a key.  A rank that
+// renders an eighth of the scene leaves most of the frame clear, and a clear tile cannot lower a minimum, so a
+// workgroup first reads the tile's word from every rank (a few bytes over each link) and then fetches the keys of
+// the ranks that touched it only.  On the bench field at eight ranks that is about a tenth of the strips.
+struct TileGrid {
+    uint32_t width, height;   // of the frame
+    uint32_t row_lo, row_hi;  // this rank's strip
+    uint32_t tiles_x;         // tiles per row of the frame
+    uint32_t tile_row0;       // first tile row that overlaps the strip
+};
+
+__device__ __forceinline__ bool tile_rect(const TileGrid& g, uint32_t& x0, uint32_t& x1, uint32_t& y0, uint32_t& y1) {
+    const uint32_t ty = g.tile_row0 + blockIdx.y;
+    x0 = blockIdx.x * kTouchTile; x1 = min(x0 + kTouchTile, g.width);
+    y0 = max(ty * kTouchTile, g.row_lo); y1 = min(ty * kTouchTile + kTouchTile, g.row_hi);
+    return x0 < x1 && y0 < y1;
 }
 
-// This rank's shaded rows, written into every peer's image, 16 bytes (four pixels) per lane.
-__global__ __launch_bounds__(256) void k_push_color(PeerTable peers, uint32_t rank, uint32_t world, size_t first_quad, size_t n_quads) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_quads) return;
-    const uint4 c = reinterpret_cast<const uint4*>(peers.color[rank])[first_quad + i];
+// This rank's strip of the composited visibility buffer: per tile, the minimum over the keys of every rank that
+// touched the tile, two keys (16 bytes) per lane, all peers' loads in flight together.  `union_now[tile]` records
+// whether any rank touched it (for the colour rows' way back).  use_flags == 0 fetches every tile from everyone.
+__global__ __launch_bounds__(256) void k_composite_tiles(PeerTable peers, uint32_t rank, uint32_t world, TileGrid g, uint32_t* union_now,
+                                                         uint32_t use_flags) {
+    __shared__ uint32_t s_mask;
+    const uint32_t tile = (g.tile_row0 + blockIdx.y) * g.tiles_x + blockIdx.x;
+    if (threadIdx.x < 64) {
+        uint32_t f = 0;
+        if (threadIdx.x < world) f = use_flags ? peers.touched[threadIdx.x][tile] : 1u;
+        const unsigned long long m = __ballot(f != 0u);
+        if (threadIdx.x == 0) {
+            s_mask = (uint32_t)m;
+            union_now[tile] = m != 0ull ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+    const uint32_t others = __builtin_amdgcn_readfirstlane(s_mask) & ~(1u << rank);
+    uint32_t x0, x1, y0, y1;
+    if (!others || !tile_rect(g, x0, x1, y0, y1)) return; // nobody else drew here: this rank's keys are the result
+    if ((g.width & 1u) == 0u) {
+        // even width: a tile row starts on a 16-byte boundary and holds whole pairs
+        const uint32_t per_row = (x1 - x0) / 2u, n = per_row * (y1 - y0);
+        for (uint32_t i = threadIdx.x; i < n; i += 256u) {
+            const uint32_t ry = i / per_row, rx = i - ry * per_row;
+            const size_t at = ((size_t)(y0 + ry) * g.width + x0) / 2u + rx;
+            ulonglong2* mine = reinterpret_cast<ulonglong2*>(peers.vis[rank]) + at;
+            ulonglong2 v[RDR_COMPOSITE_MAX_RANKS];
 #pragma unroll
-    for (uint32_t p = 0; p < RDR_COMPOSITE_MAX_RANKS; ++p)
-        if (p < world && p != rank) reinterpret_cast<uint4*>(peers.color[p])[first_quad + i] = c;
+            for (uint32_t p = 0; p < RDR_COMPOSITE_MAX_RANKS; ++p)
+                if ((others >> p) & 1u) v[p] = reinterpret_cast<const ulonglong2*>(peers.vis[p])[at];
+            ulonglong2 m = *mine;
+#pragma unroll
+            for (uint32_t p = 0; p < RDR_COMPOSITE_MAX_RANKS; ++p)
+                if ((others >> p) & 1u) {
+                    m.x = v[p].x < m.x ? v[p].x : m.x;
+                    m.y = v[p].y < m.y ? v[p].y : m.y;
+                }
+            *mine = m;
+        }
+    } else {
+        const uint32_t per_row = x1 - x0, n = per_row * (y1 - y0);
+        for (uint32_t i = threadIdx.x; i < n; i += 256u) {
+            const uint32_t ry = i / per_row, rx = i - ry * per_row;
+            const size_t at = (size_t)(y0 + ry) * g.width + x0 + rx;
+            unsigned long long m = peers.vis[rank][at];
+#pragma unroll
+            for (uint32_t p = 0; p < RDR_COMPOSITE_MAX_RANKS; ++p)
+                if ((others >> p) & 1u) {
+                    const unsigned long long v = peers.vis[p][at];
+                    m = v < m ? v : m;
+                }
+            peers.vis[rank][at] = m;
+        }
+    }
+}
+
+// This rank's shaded rows, written into every peer's image, 16 bytes (four pixels) per lane.  A tile that no
+// rank touched is all clear colour; it is written only if it was not clear the last time (`union_prev`), so
+// that a peer's image never keeps pixels of an earlier frame.  every_tile != 0 (skybox: no pixel is clear
+// colour) writes all of them.
+__global__ __launch_bounds__(256) void k_push_tiles(PeerTable peers, uint32_t rank, uint32_t world, TileGrid g, const uint32_t* union_now,
+                                                    uint32_t* union_prev, uint32_t every_tile) {
+    const uint32_t tile = (g.tile_row0 + blockIdx.y) * g.tiles_x + blockIdx.x;
+    const uint32_t now = union_now[tile], need = every_tile | now | union_prev[tile];
+    __syncthreads(); // every thread has read union_prev before it changes
+    if (threadIdx.x == 0) union_prev[tile] = now;
+    uint32_t x0, x1, y0, y1;
+    if (!need || !tile_rect(g, x0, x1, y0, y1)) return;
+    if ((g.width & 3u) == 0u) {
+        const uint32_t per_row = (x1 - x0) / 4u, n = per_row * (y1 - y0);
+        for (uint32_t i = threadIdx.x; i < n; i += 256u) {
+            const uint32_t ry = i / per_row, rx = i - ry * per_row;
+            const size_t at = ((size_t)(y0 + ry) * g.width + x0) / 4u + rx;
+            const uint4 c = reinterpret_cast<const uint4*>(peers.color[rank])[at];
+#pragma unroll
+            for (uint32_t p = 0; p < RDR_COMPOSITE_MAX_RANKS; ++p)
+                if (p < world && p != rank) reinterpret_cast<uint4*>(peers.color[p])[at] = c;
+        }
+    } else {
+        const uint32_t per_row = x1 - x0, n = per_row * (y1 - y0);
+        for (uint32_t i = threadIdx.x; i < n; i += 256u) {
+            const uint32_t ry = i / per_row, rx = i - ry * per_row;
+            const size_t at = (size_t)(y0 + ry) * g.width + x0 + rx;
+            const uint32_t c = peers.color[rank][at];
+#pragma unroll
+            for (uint32_t p = 0; p < RDR_COMPOSITE_MAX_RANKS; ++p)
+                if (p < world && p != rank) peers.color[p][at] = c;
+        }
+    }
 }
 
 } // namespace
@@ -101,7 +184,22 @@ struct rdr_composite_state {
     volatile uint32_t* timed_out = nullptr; // pinned host word
     uint32_t* timed_out_dev = nullptr;
     bool connected = false;
+    // tiles: per tile of the frame, did any rank touch it this frame / the last time this rank pushed its rows
+    uint32_t width = 0, height = 0;
+    uint32_t* union_now = nullptr;
+    uint32_t* union_prev = nullptr;
+    uint32_t pushed_lo = 0xFFFFFFFFu, pushed_hi = 0xFFFFFFFFu; // the strip union_prev describes
+    bool use_flags = true;
 };
+
+static TileGrid tile_grid(const rdr_composite_state* c, uint32_t row_lo, uint32_t row_hi, dim3& grid) {
+    TileGrid g;
+    g.width = c->width; g.height = c->height; g.row_lo = row_lo; g.row_hi = row_hi;
+    g.tiles_x = (c->width + kTouchTile - 1) / kTouchTile;
+    g.tile_row0 = row_lo / kTouchTile;
+    grid = dim3(g.tiles_x, (row_hi + kTouchTile - 1) / kTouchTile - g.tile_row0);
+    return g;
+}
 
 int rdr_composite_create(rdr_composite_state** out) {
     rdr_composite_state* c = new rdr_composite_state();
@@ -131,6 +229,9 @@ void rdr_composite_close(rdr_composite_state* c) {
         c->opened[p][0] = c->opened[p][1] = c->opened[p][2] = false;
     }
     c->connected = false;
+    if (c->union_now) (void)hipFree(c->union_now);
+    if (c->union_prev) (void)hipFree(c->union_prev);
+    c->union_now = c->union_prev = nullptr;
 }
 
 void rdr_composite_destroy(rdr_composite_state* c) {
@@ -153,13 +254,24 @@ int rdr_composite_export_handles(rdr_composite_state* c, void* vis, void* color,
     return 0;
 }
 
-int rdr_composite_open(rdr_composite_state* c, uint32_t rank, uint32_t world, const rdr_composite_handle* handles, void* vis, void* color) {
+bool rdr_composite_connected(const rdr_composite_state* c) { return c && c->connected; }
+
+int rdr_composite_open(rdr_composite_state* c, uint32_t rank, uint32_t world, const rdr_composite_handle* handles, void* vis, void* color,
+                       uint32_t width, uint32_t height) {
     RDR_CHECK(world >= 1 && world <= RDR_COMPOSITE_MAX_RANKS && rank < world, "rdr_composite_connect: rank / world out of range (at most 16 ranks)");
     RDR_CHECK(!c->connected, "rdr_composite_connect: already connected");
     c->rank = rank; c->world = world; // the frame number keeps counting across connections: phases only ever grow
+    c->width = width; c->height = height;
+    const size_t npx = (size_t)width * height, words = rdr_touched_words(width, height);
+    RDR_HIP(hipMalloc(reinterpret_cast<void**>(&c->union_now), words * 4));
+    RDR_HIP(hipMalloc(reinterpret_cast<void**>(&c->union_prev), words * 4));
+    RDR_HIP(hipMemset(c->union_now, 0, words * 4));
+    c->pushed_lo = c->pushed_hi = 0xFFFFFFFFu; // nothing is known about the peers' images yet
+    if (const char* e = std::getenv("RDR_COMPOSITE_TILE_FLAGS")) c->use_flags = std::atoi(e) != 0; // measurement hook: 0 = every tile
     for (uint32_t p = 0; p < world; ++p) {
         if (p == rank) {
             c->peers.vis[p] = static_cast<unsigned long long*>(vis);
+            c->peers.touched[p] = reinterpret_cast<uint32_t*>(c->peers.vis[p] + npx);
             c->peers.color[p] = static_cast<uint32_t*>(color);
             c->peers.ctrl[p] = c->ctrl;
             continue;
@@ -169,6 +281,7 @@ int rdr_composite_open(rdr_composite_state* c, uint32_t rank, uint32_t world, co
         std::memcpy(&h, handles[p].vis, 64);
         RDR_HIP(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
         c->peers.vis[p] = static_cast<unsigned long long*>(ptr); c->opened[p][0] = true;
+        c->peers.touched[p] = reinterpret_cast<uint32_t*>(c->peers.vis[p] + npx);
         std::memcpy(&h, handles[p].color, 64);
         RDR_HIP(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
         c->peers.color[p] = static_cast<uint32_t*>(ptr); c->opened[p][1] = true;
@@ -192,32 +305,38 @@ int rdr_composite_check(rdr_composite_state* c, const char* who) {
 }
 
 // keys of rows [row_lo, row_hi): wait for every rank's keys, take the minimum into this rank's buffer
-int rdr_composite_launch_exchange(rdr_composite_state* c, uint32_t width, uint32_t row_lo, uint32_t row_hi, hipStream_t stream) {
+int rdr_composite_launch_exchange(rdr_composite_state* c, uint32_t row_lo, uint32_t row_hi, hipStream_t stream) {
     RDR_CHECK(c->connected, "rdr_composite_exchange: not connected");
     c->frame++;
     const uint32_t base = 3u * c->frame;
     hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, stream, c->peers, c->rank, c->world, base + 1u);
     hipLaunchKernelGGL(k_wait, dim3(1), dim3(64), 0, stream, c->ctrl, c->rank, c->world, base + 1u, c->timed_out_dev);
-    const size_t first = (size_t)row_lo * width, count = (size_t)(row_hi - row_lo) * width;
-    // 16-byte units; an odd first key or count falls back to whole-buffer alignment by widening to even bounds
-    const size_t first_pair = first / 2, end_pair = (first + count + 1) / 2;
-    if (end_pair > first_pair)
-        hipLaunchKernelGGL(k_composite_min, dim3((uint32_t)((end_pair - first_pair + 255) / 256)), dim3(256), 0, stream, c->peers, c->rank, c->world,
-                           first_pair, end_pair - first_pair);
+    if (row_hi > row_lo) {
+        dim3 grid;
+        const TileGrid g = tile_grid(c, row_lo, row_hi, grid);
+        hipLaunchKernelGGL(k_composite_tiles, grid, dim3(256), 0, stream, c->peers, c->rank, c->world, g, c->union_now, c->use_flags ? 1u : 0u);
+    }
     hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, stream, c->peers, c->rank, c->world, base + 2u);
     RDR_HIP(hipGetLastError());
     return 0;
 }
 
 // colour rows [row_lo, row_hi) into every peer's image, then wait until every peer's rows are here
-int rdr_composite_launch_gather(rdr_composite_state* c, uint32_t width, uint32_t row_lo, uint32_t row_hi, hipStream_t stream) {
+int rdr_composite_launch_gather(rdr_composite_state* c, uint32_t row_lo, uint32_t row_hi, bool every_tile, hipStream_t stream) {
     RDR_CHECK(c->connected, "rdr_composite_gather: not connected");
     RDR_CHECK(c->frame > 0, "rdr_composite_gather: no exchange has run for this frame");
     const uint32_t base = 3u * c->frame;
-    const size_t first = (size_t)row_lo * width, count = (size_t)(row_hi - row_lo) * width;
-    RDR_CHECK(first % 4 == 0 && count % 4 == 0, "rdr_composite_gather: strips must start and end on a multiple of four pixels (width x rows)");
-    if (count)
-        hipLaunchKernelGGL(k_push_color, dim3((uint32_t)((count / 4 + 255) / 256)), dim3(256), 0, stream, c->peers, c->rank, c->world, first / 4, count / 4);
+    if (row_hi > row_lo) {
+        if (row_lo != c->pushed_lo || row_hi != c->pushed_hi) {
+            // a new strip: what the peers' images hold in it is unknown, so every tile counts as written before
+            RDR_HIP(hipMemsetAsync(c->union_prev, 0x01, (size_t)rdr_touched_words(c->width, c->height) * 4, stream));
+            c->pushed_lo = row_lo; c->pushed_hi = row_hi;
+        }
+        dim3 grid;
+        const TileGrid g = tile_grid(c, row_lo, row_hi, grid);
+        hipLaunchKernelGGL(k_push_tiles, grid, dim3(256), 0, stream, c->peers, c->rank, c->world, g, c->union_now, c->union_prev,
+                           (every_tile || !c->use_flags) ? 1u : 0u);
+    }
     hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, stream, c->peers, c->rank, c->world, base + 3u);
     hipLaunchKernelGGL(k_wait, dim3(1), dim3(64), 0, stream, c->ctrl, c->rank, c->world, base + 3u, c->timed_out_dev);
     RDR_HIP(hipGetLastError());

@@ -175,7 +175,9 @@ __global__ __launch_bounds__(256) void k_draw_cull(SceneView sv, FrameView fv) {
 // One workgroup's share of the visibility-buffer clear: 1024 threads, kClearPerThread 16-byte stores each,
 // consecutive threads on consecutive addresses.
 constexpr uint32_t kClearPerThread = 4;
-RDR_DEV void clear_visbuffer(const FrameView& fv, uint32_t block) {
+RDR_DEV void clear_visbuffer(const FrameView& fv, uint32_t block, uint32_t blocks) {
+    if (fv.touched) // the sort-last tile flags share the buffer's life
+        for (uint32_t i = block * 1024u + threadIdx.x; i < fv.touched_count; i += blocks * 1024u) fv.touched[i] = 0u;
     const size_t n = (size_t)fv.width * fv.height;
     const size_t base = (size_t)block * (1024u * kClearPerThread) + threadIdx.x;
 #pragma unroll
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(1024) void k_meshlet_cull(SceneView sv, FrameView f
     // and the culling grid (a few hundred workgroups waiting on dependent loads) leaves the machine idle
     // enough that the 8 bytes per pixel go out underneath it instead of in a pass of their own.
     if (blockIdx.x >= fv.grid.cull_blocks) {
-        clear_visbuffer(fv, blockIdx.x - fv.grid.cull_blocks);
+        clear_visbuffer(fv, blockIdx.x - fv.grid.cull_blocks, gridDim.x - fv.grid.cull_blocks);
         return;
     }
     const uint32_t lane = lane_id();
@@ -369,6 +371,32 @@ RDR_DEV void project_xy(float cx, float cy, float cw, float half_w, float half_h
 RDR_DEV bool vert_needs_clip(float x, float y, float z, float w) {
     const float g = kGuardBand * w;
     return !(w >= z) || !(fabsf(x) <= g) || !(fabsf(y) <= g);
+}
+
+// Sort-last tile flags (FrameView::touched): the tile of a pixel / every tile of a pixel box that is about to be
+// scanned.  Plain stores of the same value: which lane or wave wins does not matter.
+RDR_DEV void touch_pixel(const FrameView& fv, int px, int py) {
+    if (fv.touched) fv.touched[(uint32_t)py / kTouchTile * fv.touched_x + (uint32_t)px / kTouchTile] = 1u;
+}
+// k_raster marks per meshlet, outside its triangle loop (in there the flags would cost the opaque instantiation
+// a wave per SIMD): every tile under the pixel box of the meshlet's vertices that need no clipping.  Triangles
+// scanned by a lane have three such vertices, so their pixels lie inside; the others go to kernels that mark
+// for themselves.  (X, Y): the lane's snapped 24.8 vertex, `valid`: it has one.
+RDR_DEV void touch_meshlet(const FrameView& fv, bool valid, int32_t X, int32_t Y, uint32_t lane) {
+    int32_t x0 = valid ? X : 0x7FFFFFFF, y0 = valid ? Y : 0x7FFFFFFF, x1 = valid ? X : -0x7FFFFFFF, y1 = valid ? Y : -0x7FFFFFFF;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        x0 = min(x0, __shfl_xor(x0, o, 64)); y0 = min(y0, __shfl_xor(y0, o, 64));
+        x1 = max(x1, __shfl_xor(x1, o, 64)); y1 = max(y1, __shfl_xor(y1, o, 64));
+    }
+    if (x0 > x1) return; // no usable vertex
+    // a pixel box never reaches past floor(min / 256) .. floor(max / 256) (setup_triangle rounds inwards)
+    const int32_t px0 = max(x0 >> 8, 0), py0 = max(y0 >> 8, 0);
+    const int32_t px1 = min(x1 >> 8, (int32_t)fv.width - 1), py1 = min(y1 >> 8, (int32_t)fv.height - 1);
+    if (px0 > px1 || py0 > py1) return;
+    const uint32_t tx0 = (uint32_t)px0 / kTouchTile, ty0 = (uint32_t)py0 / kTouchTile;
+    const uint32_t nx = (uint32_t)px1 / kTouchTile - tx0 + 1u, n = nx * ((uint32_t)py1 / kTouchTile - ty0 + 1u);
+    for (uint32_t i = lane; i < n; i += 64u) fv.touched[(ty0 + i / nx) * fv.touched_x + tx0 + i % nx] = 1u;
 }
 
 RDR_DEV void emit_fragment(const FrameView& fv, int px, int py, float z, uint32_t id) {
@@ -542,6 +570,7 @@ RDR_DEV uint32_t scan_wave(const SceneView& sv, const FrameView& fv, const TriSe
         const int px = t.px0 + (sidx % stamps_x) * 8 + (int)(lane & 7u);
         const int py = t.py0 + (sidx / stamps_x) * 8 + (int)(lane >> 3);
         if (px <= t.px1 && py <= t.py1) {
+            touch_pixel(fv, px, py);
             I e01, e12, e20;
             edges_at<I>(t, px, py, e01, e12, e20);
             frags += shade_sample<I, MASK>(sv, fv, t, at, px, py, e01, e12, e20, id);
@@ -573,7 +602,9 @@ struct MaskVertexLds<true> {
 // MASK = false: meshlets of opaque draws (front of the visible list); MASK = true:
 // meshlets of alpha-tested draws (back of the list).  Two instantiations so that the
 // opaque one carries no uv / texture state in registers.
-template <bool MASK>
+// TOUCH: keep the sort-last tile flags (an instantiation of its own: the few registers the marking needs would
+// cost the plain opaque one its fifth wave per SIMD).
+template <bool MASK, bool TOUCH>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : 1))) void k_raster(SceneView sv, FrameView fv) {
     __shared__ MeshletLds lds;
     __shared__ MaskVertexLds<MASK> mlds;
@@ -642,6 +673,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : 1
         __syncthreads();
         if (has_next && lane < (vm_next.counts & 0xFFFFu)) // in flight during the triangle phase
             vi_next = sv.meshlet_vertices[vm_next.vertex_offset + lane] + vm_next.mesh_vertex_offset;
+        if (TOUCH) touch_meshlet(fv, lane < m.vertex_count && lds.clip[lane] == 0u, lds.X[lane], lds.Y[lane], lane);
 
         // Triangle phase 1: the mesh shader's cull tests, two triangles per lane; the survivors (about
         // four in ten on a closed mesh) are packed into an LDS queue so that phase 2 runs on full lanes.
@@ -969,6 +1001,7 @@ __global__ __launch_bounds__(256) void k_alpha_frag(SceneView sv, FrameView fv) 
         ft.valid = true;
         int32_t e01, e12, e20;
         edges_at<int32_t>(ft, px, py, e01, e12, e20);
+        touch_pixel(fv, px, py);
         frags += shade_sample<int32_t, true>(sv, fv, ft, at, px, py, e01, e12, e20, r.id);
     }
     if (fv.collect_stats) {
@@ -1500,6 +1533,7 @@ __global__ __launch_bounds__((kTilePart / B) * (kTilePart / B)) void k_tile_rast
         }
         // merge the block into the visibility buffer: rows of B keys, contiguous
         if (block_on_screen) {
+            bool any = false;
 #pragma unroll
             for (int j = 0; j < B; ++j) {
                 if (by0 + j >= (int)fv.height) continue;
@@ -1509,10 +1543,12 @@ __global__ __launch_bounds__((kTilePart / B) * (kTilePart / B)) void k_tile_rast
                     if (bx0 + i >= (int)fv.width) continue;
                     const unsigned long long k = keys[j * B + i];
                     if (k == RDR_VIS_CLEAR) continue;
+                    any = true;
                     if (shared_tile) atomicMin(&row[i], k);
                     else if (k < row[i]) row[i] = k;
                 }
             }
+            if (any) touch_pixel(fv, bx0, by0); // B divides the tile edge: the block lies in one tile
         }
     }
     if (fv.collect_stats) {
@@ -1662,10 +1698,14 @@ int rdr_geometry_residency(GeometryResidency* out) {
     RDR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
     RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_meshlet_cull<kPhaseLate>, 1024, 0));
     out->meshlet_cull = (uint32_t)(n * cus);
-    RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_raster<false>, 64, 0));
+    RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (k_raster<false, false>), 64, 0));
     out->raster = (uint32_t)(n * cus);
-    RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_raster<true>, 64, 0));
+    RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (k_raster<true, false>), 64, 0));
     out->raster_mask = (uint32_t)(n * cus);
+    RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (k_raster<false, true>), 64, 0));
+    out->raster_touch = (uint32_t)(n * cus);
+    RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (k_raster<true, true>), 64, 0));
+    out->raster_mask_touch = (uint32_t)(n * cus);
     RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mid_raster, 256, 0));
     out->mid_raster = (uint32_t)(n * cus);
     RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_alpha_frag, 256, 0));
@@ -1687,14 +1727,17 @@ int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t st
         // a scene without draws: nothing else runs, so the clear is a launch of its own and zeroes both sets of heads
         hipLaunchKernelGGL(k_clear, dim3(std::max(clear_blocks, 1u)), dim3(256), 0, stream, fv.vis, npx, fv.counters, fv.tile_count, n_tiles);
         hipLaunchKernelGGL(k_clear, dim3(std::max((n_tiles + 255u) / 256u, 1u)), dim3(256), 0, stream, fv.vis, (size_t)0, fv.counters_next, fv.tile_count_next, n_tiles);
+        if (fv.touched) RDR_HIP(hipMemsetAsync(fv.touched, 0, (size_t)fv.touched_count * 4, stream));
     }
     if (ev) RDR_HIP(hipEventRecord(ev[1], stream));
     // one pass of the rasterisers over the current work lists
     auto raster_lists = [&](const FrameView& f, hipEvent_t* mid_event) {
         // persistent grids: the work-list lengths live in device memory
-        hipLaunchKernelGGL(k_raster<false>, dim3(f.grid.raster_blocks), dim3(64), 0, stream, sv, f);
+        if (f.touched) hipLaunchKernelGGL((k_raster<false, true>), dim3(f.grid.raster_blocks), dim3(64), 0, stream, sv, f);
+        else hipLaunchKernelGGL((k_raster<false, false>), dim3(f.grid.raster_blocks), dim3(64), 0, stream, sv, f);
         if (sv.masked_meshlets) { // a scene without alpha-tested draws has nothing for these two (an empty launch costs 4-5 us)
-            hipLaunchKernelGGL(k_raster<true>, dim3(f.grid.raster_mask_blocks), dim3(64), 0, stream, sv, f);
+            if (f.touched) hipLaunchKernelGGL((k_raster<true, true>), dim3(f.grid.raster_mask_blocks), dim3(64), 0, stream, sv, f);
+            else hipLaunchKernelGGL((k_raster<true, false>), dim3(f.grid.raster_mask_blocks), dim3(64), 0, stream, sv, f);
             hipLaunchKernelGGL(k_alpha_frag, dim3(f.grid.frag_blocks), dim3(256), 0, stream, sv, f);
         }
         hipLaunchKernelGGL(k_tile_setup, dim3(1024), dim3(64), 0, stream, sv, f); // also feeds k_mid_raster

@@ -337,6 +337,12 @@ struct FrameView {
     // for larger or clipped triangles) it goes to the tile path.
     uint32_t lane_max_pixels, mid_max_pixels;
     uint32_t skybox; // 1: uncovered pixels get the skybox (k_skybox) instead of the clear colour
+    // Sort-last bookkeeping, only while a peer-to-peer exchange is connected (null otherwise): one word per
+    // kTouchTile x kTouchTile pixel tile, non-zero when a rasteriser may have written a key into the tile this
+    // frame.  It lives behind the visibility buffer in the same allocation, is zeroed with it, and lets the
+    // peers skip the tiles this rank left clear.
+    uint32_t* touched;
+    uint32_t touched_x, touched_count; // tiles per row, tiles in all
     uint32_t list_heads_zero; // host side: pixel_count / shadow_overflow are still as the geometry pass's clear left them
     // Two-phase occlusion culling (result-neutral): state kept from the previous frame and the
     // depth pyramid of the early phase.  Level l holds, per 2^(l+1) x 2^(l+1) pixel block, the
@@ -382,6 +388,7 @@ void rdr_build_tlas(const rdr_scene_desc& s, const float* transforms, HostBvh& i
 int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev);
 struct GeometryResidency {
     uint32_t meshlet_cull, raster, raster_mask, mid_raster, alpha_frag, tile_raster; // resident workgroups on the whole device
+    uint32_t raster_touch, raster_mask_touch; // k_raster's instantiations that keep the sort-last tile flags
 };
 int rdr_geometry_residency(GeometryResidency* out);
 int rdr_launch_shadow(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev); // classify + shadow rays
@@ -392,11 +399,18 @@ int rdr_composite_create(rdr_composite_state** out);
 void rdr_composite_close(rdr_composite_state* c);
 void rdr_composite_destroy(rdr_composite_state* c);
 int rdr_composite_export_handles(rdr_composite_state* c, void* vis, void* color, rdr_composite_handle* out);
-int rdr_composite_open(rdr_composite_state* c, uint32_t rank, uint32_t world, const rdr_composite_handle* handles, void* vis, void* color);
+int rdr_composite_open(rdr_composite_state* c, uint32_t rank, uint32_t world, const rdr_composite_handle* handles, void* vis, void* color,
+                       uint32_t width, uint32_t height);
+bool rdr_composite_connected(const rdr_composite_state* c);
 int rdr_composite_check(rdr_composite_state* c, const char* who);
 bool rdr_composite_timed_out(const rdr_composite_state* c); // a bounded wait gave up (not cleared by asking)
-int rdr_composite_launch_exchange(rdr_composite_state* c, uint32_t width, uint32_t row_lo, uint32_t row_hi, hipStream_t stream);
-int rdr_composite_launch_gather(rdr_composite_state* c, uint32_t width, uint32_t row_lo, uint32_t row_hi, hipStream_t stream);
+int rdr_composite_launch_exchange(rdr_composite_state* c, uint32_t row_lo, uint32_t row_hi, hipStream_t stream);
+int rdr_composite_launch_gather(rdr_composite_state* c, uint32_t row_lo, uint32_t row_hi, bool every_tile, hipStream_t stream);
+// Edge of the tiles of FrameView::touched, and the words to reserve for them behind a width x height visibility buffer.
+constexpr uint32_t kTouchTile = 32;
+inline uint32_t rdr_touched_words(uint32_t width, uint32_t height) {
+    return ((width + kTouchTile - 1) / kTouchTile) * ((height + kTouchTile - 1) / kTouchTile);
+}
 size_t rdr_bc_level_bytes(uint32_t format, uint32_t width, uint32_t height);
 int rdr_launch_decode_bc(uint32_t format, uint32_t width, uint32_t height, const uint8_t* blocks, uint32_t* out, hipStream_t stream);
 int rdr_launch_resolve(const SceneView& sv, const FrameView& fv, uint32_t* out_xy, hipStream_t stream);

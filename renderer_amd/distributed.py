@@ -255,14 +255,18 @@ class SortLastPipeline:
                 f.composite = "reduce_scatter" if scatter_ok else "all_reduce"
 
     def _p2p_matches_collective(self, height, rank, world):
-        """One frame composited both ways on slot 0: the keys of this rank's rows and the gathered image must be
-        identical on every rank.  The peer-to-peer frame contains no collective, so a rank on which it fails (an
-        exception, a peer that never arrives) still meets the others in the agreement that follows it."""
+        """Probe frames composited both ways on slot 0: the keys of this rank's rows and the gathered image must be
+        identical on every rank.  Two peer-to-peer frames with different suns and cameras run first, and the second
+        is the one compared: a machine on which a rank's caches kept lines of a peer's buffers from the frame before
+        would pass a single frame and fail this.  The peer-to-peer frames contain no collective, so a rank on which
+        they fail (an exception, a peer that never arrives) still meets the others in the agreement that follows."""
         f, stream = self.slots[0]
         lo, hi = row_range(height, rank, world)
         keys = image = None
         with torch.cuda.stream(stream):
             try:
+                f.step(sun=(0.3, 0.8, 0.52))  # another sun: other shadows, the same keys
+                f.step(camera=self._probe_camera(f.r))  # another view: other keys everywhere
                 f.step()
                 torch.cuda.synchronize()
                 ok = f.r.frame_status() == 0
@@ -278,6 +282,18 @@ class SortLastPipeline:
             same = bool(torch.equal(keys, f.vis.view(height, -1)[lo:hi])) and bool(torch.equal(image, f.color))
             f.composite = "p2p"
         return _all_agree(same)
+
+    @staticmethod
+    def _probe_camera(renderer):
+        """The scene's camera moved sideways and turned a little (None when the renderer does not expose its scene:
+        the probe then repeats the default view)."""
+        cam = getattr(getattr(renderer, "scene", None), "camera", None)
+        if cam is None:
+            return None
+        from .scene import Camera
+        px, py, pz = cam.position
+        dx, dy, dz = cam.direction
+        return Camera((px + 2.5, py + 1.0, pz - 1.5), (dx + 0.15, dy + 0.05, dz))
 
     @property
     def composite(self):

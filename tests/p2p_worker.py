@@ -12,7 +12,7 @@ from renderer_amd import Renderer, RendererConfig, synth  # noqa: E402
 from renderer_amd.distributed import instance_range, row_range  # noqa: E402
 from renderer_amd.scene import Camera  # noqa: E402
 
-W, H = 256, 144
+W, H = (int(v) for v in os.environ.get("P2P_SIZE", "256x144").split("x"))
 
 
 def publish(path, data):
@@ -33,7 +33,7 @@ def main():
     rank, world, d = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     device = int(os.environ.get("P2P_DEVICE", "0"))
     scene = synth.make_field(60, 3, lods=1, alpha_fraction=0.3, with_env=True, prepared=True)
-    conf = RendererConfig(cull_enabled=False)
+    conf = RendererConfig(cull_enabled=False, skybox=os.environ.get("P2P_SKYBOX") == "1")
     r = Renderer(W, H, conf, device=device)
     r.set_scene(scene)
     r.set_partition(*instance_range(scene.meshlet_visibility_count, rank, world))
@@ -77,7 +77,9 @@ def main():
     whole.set_scene(scene)
     base = scene.camera
     cams = [base, Camera(tuple(np.add(base.position, (3.0, 1.0, -2.0))), base.direction),
-            Camera(tuple(np.add(base.position, (-4.0, 2.0, 5.0))), tuple(np.add(base.direction, (0.1, 0.05, 0.0))))]
+            Camera(tuple(np.add(base.position, (-4.0, 2.0, 5.0))), tuple(np.add(base.direction, (0.1, 0.05, 0.0)))),
+            # looking away: an empty frame (every tile the last frame covered must be cleared in every peer's image), then back
+            Camera(base.position, tuple(-np.asarray(base.direction))), base]
     frames = []
     for cam in cams:  # frames back to back, no host synchronisation inside a frame
         r.render_visbuffer(cam)
