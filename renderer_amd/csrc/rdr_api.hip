@@ -538,6 +538,9 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
         const size_t n_tiles = (size_t)((width + 63) / 64) * ((height + 63) / 64);
         if (r->tile_count.alloc(2 * n_tiles) || r->tile_offset.alloc(n_tiles) || r->tile_cursor.alloc(n_tiles)) return 1;
         RDR_HIP(hipMemset(r->tile_count.ptr, 0, 2 * n_tiles * 4));
+        RDR_HIP(hipMemset(r->tile_cursor.ptr, 0, n_tiles * 4)); // k_tile_fill expects it zero; k_tile_raster leaves it so
+        // k_tile_fill keeps one bin offset per tile in LDS (64 KiB: 15 872 tiles, e.g. 11 264 x 5 760 pixels)
+        RDR_CHECK(n_tiles * 4 + 2056 <= 65536, "rdr_create: frame too large for the tile path (more than 15 872 tiles of 64 x 64 pixels)");
     }
     RDR_HIP(hipMemset(r->counters.ptr, 0, 2 * sizeof(FrameCounters)));
     {

@@ -1053,14 +1053,12 @@ RDR_DEV SnapVert snap_clip_vert(const ClipVert& v, float half_w, float half_h) {
 
 // ------------------------------------------------------------------------------
 // Tile path: clipped, large or pixel-heavy triangles.
-//   k_tile_setup  clip -> fan -> snap -> SetupTri records
-//   k_tile_bin<0> count the records per 64x64 tile
-//   k_tile_scan   prefix sum of the per-tile counts -> bin offsets
-//   k_tile_bin<1> write each record's index into the bins of the tiles it touches
-//   k_tile_raster one workgroup per tile: bins staged through LDS in batches, each
-//                 thread owns a 4x4 pixel block whose 16 keys stay in registers, then
-//                 one read-min-write of the tile (no atomics: the tile has one owner
-//                 and the per-meshlet rasteriser has finished).
+//   k_tile_setup  clip -> fan -> snap -> SetupTri records, counted per 64x64 tile as they are made
+//   k_tile_fill   prefix sum of the per-tile counts -> bin offsets and the job list, then each
+//                 record's index into the bins of the tiles it touches
+//   k_tile_raster jobs of kTileJob records over a 32x32 piece of a tile: the records staged
+//                 through LDS, each thread owns a 2x2 pixel block whose keys stay in registers,
+//                 merged into the visibility buffer at the end.
 // ------------------------------------------------------------------------------
 
 struct EdgeEq {
@@ -1097,6 +1095,43 @@ RDR_DEV bool tile_touched(const SetupTri& t, uint32_t tx, uint32_t ty) {
     const EdgeEq e20 = make_edge(t.X2, t.Y2, t.X0, t.Y0, x0, y0);
     return edge_max(e01, kTile - 1, kTile - 1) + e01.bias >= 0 && edge_max(e12, kTile - 1, kTile - 1) + e12.bias >= 0 &&
            edge_max(e20, kTile - 1, kTile - 1) + e20.bias >= 0;
+}
+
+// Binning of the set-up records into 64x64 tiles, two passes over the (record, tile) pairs where the record may
+// cover a pixel of the tile.  Counting happens where the records are made: the wave of k_tile_setup that produced
+// a record adds it to its tiles' counts (count_tiles).  k_tile_fill then turns the counts into bin offsets and
+// writes the record indices into the bins.  In both, a lane walks the tiles of its own record while there are at
+// most kLaneTiles of them; records spanning more tiles are taken one at a time by the whole wave, so that a
+// full-screen triangle costs tens of steps rather than thousands.
+constexpr uint32_t kLaneTiles = 4;
+
+RDR_DEV void count_tiles(const FrameView& fv, const SetupTri& t, bool valid, uint32_t lane) {
+    uint32_t tx0 = 0, ty0 = 0, tw = 1, n_tiles = 0;
+    if (valid) {
+        tx0 = t.px0 / kTile; ty0 = t.py0 / kTile;
+        tw = t.px1 / kTile - tx0 + 1u;
+        n_tiles = tw * (t.py1 / kTile - ty0 + 1u);
+    }
+    if (n_tiles <= kLaneTiles)
+        for (uint32_t q = 0; q < n_tiles; ++q)
+            if (tile_touched(t, tx0 + q % tw, ty0 + q / tw)) atomicAdd(&fv.tile_count[(ty0 + q / tw) * fv.tiles_x + tx0 + q % tw], 1u);
+    unsigned long long wide = __ballot(n_tiles > kLaneTiles);
+    while (wide) {
+        const int src = __ffsll((long long)wide) - 1;
+        wide &= wide - 1ull;
+        SetupTri w; // what tile_touched reads of the record in lane `src`
+        w.X0 = __shfl(t.X0, src, 64); w.Y0 = __shfl(t.Y0, src, 64); w.X1 = __shfl(t.X1, src, 64);
+        w.Y1 = __shfl(t.Y1, src, 64); w.X2 = __shfl(t.X2, src, 64); w.Y2 = __shfl(t.Y2, src, 64);
+        const uint32_t lo = __shfl((uint32_t)t.px0 | ((uint32_t)t.py0 << 16), src, 64);
+        const uint32_t hi = __shfl((uint32_t)t.px1 | ((uint32_t)t.py1 << 16), src, 64);
+        w.px0 = (uint16_t)lo; w.py0 = (uint16_t)(lo >> 16); w.px1 = (uint16_t)hi; w.py1 = (uint16_t)(hi >> 16);
+        const uint32_t wx0 = w.px0 / kTile, wy0 = w.py0 / kTile, ww = w.px1 / kTile - wx0 + 1u;
+        const uint32_t wn = ww * (w.py1 / kTile - wy0 + 1u);
+        for (uint32_t q = lane; q < wn; q += 64u) {
+            const uint32_t tx = wx0 + q % ww, ty = wy0 + q / ww;
+            if (tile_touched(w, tx, ty)) atomicAdd(&fv.tile_count[ty * fv.tiles_x + tx], 1u);
+        }
+    }
 }
 
 // The polygon being clipped lives in LDS, a column per lane (vertex- and component-major, so the
@@ -1223,108 +1258,99 @@ __global__ __launch_bounds__(64) void k_tile_setup(SceneView sv, FrameView fv) {
             uint32_t slot0 = 0;
             if ((int)lane == leader) slot0 = atomicAdd(&fv.counters->setup_count, (uint32_t)__popcll(m));
             slot0 = __shfl(slot0, leader, 64);
-            if (!ok) continue;
             const uint32_t slot = slot0 + ballot_rank(m);
-            if (slot >= fv.setup_capacity) {
-                atomicAdd(&fv.counters->setup_overflow, 1u);
-                continue;
+            const bool stored = ok && slot < fv.setup_capacity;
+            if (ok && !stored) atomicAdd(&fv.counters->setup_overflow, 1u);
+            if (stored) {
+                fv.setup[slot] = t;
+                if (masked) fv.setup_mask[slot] = mk;
             }
-            fv.setup[slot] = t;
-            if (masked) fv.setup_mask[slot] = mk;
+            count_tiles(fv, t, stored, lane); // the whole wave: wide records are walked by all lanes
         }
     }
 }
 
-// Visit every (record, tile) pair where the record may cover a pixel of the tile.  A lane
-// walks the tiles of its own record while there are at most kLaneTiles of them; records
-// spanning more tiles are taken one at a time by the whole wave, 64 tiles per step, so
-// that a full-screen triangle costs tens of steps rather than thousands.  FILL = false
-// counts per tile, FILL = true writes the record index into the tile's bin.
-constexpr uint32_t kLaneTiles = 4;
-
-template <bool FILL>
-RDR_DEV void bin_visit(const FrameView& fv, const SetupTri& t, uint32_t record, uint32_t tx, uint32_t ty) {
-    if (!tile_touched(t, tx, ty)) return;
-    const uint32_t tile = ty * fv.tiles_x + tx;
-    if (FILL) {
-        const uint32_t slot = fv.tile_offset[tile] + atomicAdd(&fv.tile_cursor[tile], 1u);
-        if (slot < fv.bin_capacity) fv.bin_entries[slot] = record;
-    } else {
-        atomicAdd(&fv.tile_count[tile], 1u);
-    }
-}
-
-// Prefix sum of the per-tile counts -> bin offsets, and the job list of k_tile_raster: a tile's bin is cut
-// into jobs of kTileJob records, so that a tile under many expensive (large, alpha-tested) triangles is
-// worked on by several workgroups instead of setting the kernel's length alone.  Both sums travel in one
-// 64-bit value: entries in the low 40 bits, jobs above.
-template <uint32_t N>
-RDR_DEV void tile_scan(const FrameView& fv, unsigned long long* partial /* N entries of LDS */) {
-    const uint32_t n_tiles = fv.tiles_x * fv.tiles_y;
-    const uint32_t per = (n_tiles + N - 1u) / N;
-    const uint32_t first = threadIdx.x * per, last = min(first + per, n_tiles);
-    unsigned long long sum = 0;
-    for (uint32_t i = first; i < last; ++i) {
-        const uint32_t c = fv.tile_count[i];
-        sum += (unsigned long long)c + ((unsigned long long)((c + kTileJob - 1u) / kTileJob * kTileParts) << 40);
-    }
-    partial[threadIdx.x] = sum;
-    __syncthreads();
-    for (uint32_t o = 1; o < N; o <<= 1) { // inclusive Hillis-Steele scan
-        const unsigned long long v = threadIdx.x >= o ? partial[threadIdx.x - o] : 0ull;
-        __syncthreads();
-        partial[threadIdx.x] += v;
-        __syncthreads();
-    }
-    const unsigned long long before = partial[threadIdx.x] - sum;
-    uint32_t run = (uint32_t)(before & ((1ull << 40) - 1ull)), listed = (uint32_t)(before >> 40);
-    for (uint32_t i = first; i < last; ++i) {
-        const uint32_t c = fv.tile_count[i];
-        fv.tile_offset[i] = run;
-        fv.tile_cursor[i] = 0u;
-        for (uint32_t r = 0; r < c; r += kTileJob)
-            for (uint32_t part = 0; part < kTileParts; ++part, ++listed)
-                if (listed < fv.tile_list_capacity) fv.tile_list[listed] = make_uint2(i, r | part); // kTileJob >= kTileParts: the low bits are free
-        run += c;
-    }
-    if (threadIdx.x == N - 1u) {
-        const unsigned long long total = partial[N - 1u] & ((1ull << 40) - 1ull);
-        fv.counters->bin_total = (uint32_t)min(total, 0xFFFFFFFFull);
-        fv.counters->tile_nonempty = (uint32_t)min(partial[N - 1u] >> 40, (unsigned long long)fv.tile_list_capacity);
-        if (total > fv.bin_capacity) fv.counters->bin_overflow = 1u;
-    }
-}
-
-// The prefix sum runs as a launch of its own between the counting and the filling pass.  Folding it into the tail
-// of the counting pass (last workgroup to finish scans, found by a ticket behind a release fence) was slower: 512
-// fences and tickets and a 256-thread scan took 18 us on a frame with nothing to bin, the two launches 8.6 us.
-__global__ __launch_bounds__(1024) void k_tile_scan(FrameView fv) {
-    __shared__ unsigned long long partial[1024];
-    tile_scan<1024>(fv, partial);
-}
-
+// Bin offsets and the bins.  Every workgroup first repeats the prefix sum over the per-tile counts for itself
+// (a few thousand counts, served by the L2: cheaper than a launch in between, which costs 4-5 us of dependency
+// latency even on a frame with nothing to bin; a last-workgroup ticket behind a release fence was slower still)
+// and keeps the offsets in LDS.  What later kernels need in memory is written once, spread over the workgroups:
+// the offsets, and the job list of k_tile_raster (a tile's bin is cut into jobs of kTileJob records over the
+// kTileParts pieces of the tile, so that a tile under many expensive triangles is worked on by several
+// workgroups instead of setting that kernel's length alone).  Both running sums travel in one 64-bit value:
+// entries in the low 40 bits, jobs above.  Then the records are visited as in count_tiles and written into
+// their tiles' bins.  FrameView::tile_cursor is zero on entry (k_tile_raster leaves it so).
 constexpr uint32_t kBinChunk = 4;
-template <bool FILL>
-__global__ __launch_bounds__(256) void k_tile_bin(FrameView fv) {
+__global__ __launch_bounds__(256) void k_tile_fill(FrameView fv) {
+    extern __shared__ uint32_t tile_off[]; // n_tiles offsets, then the scan's 256 partial sums (64-bit)
     const uint32_t lane = lane_id();
     const uint32_t count = min(fv.counters->setup_count, fv.setup_capacity);
+    if (count == 0u) { // nothing was set up: empty bins, no jobs
+        if (blockIdx.x == 0 && threadIdx.x == 0) { fv.counters->bin_total = 0u; fv.counters->tile_nonempty = 0u; }
+        return;
+    }
+    const uint32_t n_tiles = fv.tiles_x * fv.tiles_y;
+    unsigned long long* partial = reinterpret_cast<unsigned long long*>(tile_off + ((n_tiles + 1u) & ~1u));
+    {
+        const uint32_t per = (n_tiles + 255u) / 256u;
+        const uint32_t first = min(threadIdx.x * per, n_tiles), last = min(first + per, n_tiles);
+        unsigned long long sum = 0;
+        for (uint32_t i = first; i < last; ++i) {
+            const uint32_t c = fv.tile_count[i];
+            sum += (unsigned long long)c + ((unsigned long long)((c + kTileJob - 1u) / kTileJob * kTileParts) << 40);
+        }
+        partial[threadIdx.x] = sum;
+        __syncthreads();
+        for (uint32_t o = 1; o < 256u; o <<= 1) { // inclusive Hillis-Steele scan
+            const unsigned long long v = threadIdx.x >= o ? partial[threadIdx.x - o] : 0ull;
+            __syncthreads();
+            partial[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const unsigned long long before = partial[threadIdx.x] - sum;
+        uint32_t run = (uint32_t)(before & ((1ull << 40) - 1ull)), listed = (uint32_t)(before >> 40);
+        const bool writer = threadIdx.x % gridDim.x == blockIdx.x; // this thread's tiles go to memory from this workgroup
+        for (uint32_t i = first; i < last; ++i) {
+            const uint32_t c = fv.tile_count[i];
+            tile_off[i] = run;
+            if (writer) {
+                fv.tile_offset[i] = run;
+                for (uint32_t r = 0; r < c; r += kTileJob)
+                    for (uint32_t part = 0; part < kTileParts; ++part, ++listed)
+                        if (listed < fv.tile_list_capacity) fv.tile_list[listed] = make_uint2(i, r | part); // kTileJob >= kTileParts: the low bits are free
+            }
+            run += c;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 255u) {
+            const unsigned long long total = partial[255] & ((1ull << 40) - 1ull);
+            fv.counters->bin_total = (uint32_t)min(total, 0xFFFFFFFFull);
+            fv.counters->tile_nonempty = (uint32_t)min(partial[255] >> 40, (unsigned long long)fv.tile_list_capacity);
+            if (total > fv.bin_capacity) fv.counters->bin_overflow = 1u;
+        }
+        __syncthreads();
+    }
     // A wave takes kBinChunk records at a time, not 64: records that cover many tiles are walked by
     // the whole wave one after another, and a frame usually has few records but some very wide ones
     // (walls, floors), so small chunks spread those over many more waves.
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t base_i = wave * kBinChunk; base_i < count; base_i += n_waves * kBinChunk) {
         const uint32_t i = base_i + lane;
-        uint32_t tx0 = 0, ty0 = 0, tw = 0, n_tiles = 0;
+        uint32_t tx0 = 0, ty0 = 0, tw = 1, nt = 0;
         SetupTri t;
         if (lane < kBinChunk && i < count) {
             t = fv.setup[i];
             tx0 = t.px0 / kTile; ty0 = t.py0 / kTile;
             tw = t.px1 / kTile - tx0 + 1u;
-            n_tiles = tw * (t.py1 / kTile - ty0 + 1u);
+            nt = tw * (t.py1 / kTile - ty0 + 1u);
         }
-        if (n_tiles <= kLaneTiles)
-            for (uint32_t q = 0; q < n_tiles; ++q) bin_visit<FILL>(fv, t, i, tx0 + q % tw, ty0 + q / tw);
-        unsigned long long wide = __ballot(n_tiles > kLaneTiles);
+        if (nt <= kLaneTiles)
+            for (uint32_t q = 0; q < nt; ++q) {
+                const uint32_t tx = tx0 + q % tw, ty = ty0 + q / tw;
+                if (!tile_touched(t, tx, ty)) continue;
+                const uint32_t tile = ty * fv.tiles_x + tx;
+                const uint32_t slot = tile_off[tile] + atomicAdd(&fv.tile_cursor[tile], 1u);
+                if (slot < fv.bin_capacity) fv.bin_entries[slot] = i;
+            }
+        unsigned long long wide = __ballot(nt > kLaneTiles);
         while (wide) {
             const int src = __ffsll((long long)wide) - 1;
             wide &= wide - 1ull;
@@ -1332,7 +1358,7 @@ __global__ __launch_bounds__(256) void k_tile_bin(FrameView fv) {
             const SetupTri w = fv.setup[record]; // the same address in every lane: one broadcast load
             const uint32_t wx0 = w.px0 / kTile, wy0 = w.py0 / kTile, ww = w.px1 / kTile - wx0 + 1u;
             const uint32_t wn = ww * (w.py1 / kTile - wy0 + 1u);
-            // four tiles per lane and round: the fill's atomics return a value (the slot), and one round
+            // four tiles per lane and round: the atomics return a value (the slot), and one round
             // trip per 64 tiles was most of this kernel's length on records that span the screen
             for (uint32_t q0 = lane; q0 < wn; q0 += 256u) {
                 bool touched[4];
@@ -1344,19 +1370,13 @@ __global__ __launch_bounds__(256) void k_tile_bin(FrameView fv) {
                     touched[k] = q < wn && tile_touched(w, tx, ty);
                     tiles[k] = ty * fv.tiles_x + tx;
                 }
-                if (FILL) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) got[k] = touched[k] ? atomicAdd(&fv.tile_cursor[tiles[k]], 1u) : 0u;
+                for (int k = 0; k < 4; ++k) got[k] = touched[k] ? atomicAdd(&fv.tile_cursor[tiles[k]], 1u) : 0u;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (!touched[k]) continue;
-                        const uint32_t slot = fv.tile_offset[tiles[k]] + got[k];
-                        if (slot < fv.bin_capacity) fv.bin_entries[slot] = record;
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (touched[k]) atomicAdd(&fv.tile_count[tiles[k]], 1u);
+                for (int k = 0; k < 4; ++k) {
+                    if (!touched[k]) continue;
+                    const uint32_t slot = tile_off[tiles[k]] + got[k];
+                    if (slot < fv.bin_capacity) fv.bin_entries[slot] = record;
                 }
             }
         }
@@ -1383,7 +1403,10 @@ __global__ __launch_bounds__((kTilePart / B) * (kTilePart / B)) void k_tile_rast
         const uint32_t n_words = (uint32_t)(sizeof(FrameCounters) / 4u), n_tiles = fv.tiles_x * fv.tiles_y;
         for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n_words + n_tiles; w += gridDim.x * blockDim.x) {
             if (w < n_words) reinterpret_cast<uint32_t*>(fv.counters_next)[w] = 0u;
-            else fv.tile_count_next[w - n_words] = 0u;
+            else {
+                fv.tile_count_next[w - n_words] = 0u;
+                fv.tile_cursor[w - n_words] = 0u; // k_tile_fill is done with it and expects it zero the next time
+            }
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1743,9 +1766,7 @@ int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t st
         hipLaunchKernelGGL(k_tile_setup, dim3(1024), dim3(64), 0, stream, sv, f); // also feeds k_mid_raster
         hipLaunchKernelGGL(k_mid_raster, dim3(f.grid.mid_blocks), dim3(256), 0, stream, sv, f);
         if (mid_event) (void)hipEventRecord(*mid_event, stream);
-        hipLaunchKernelGGL(k_tile_bin<false>, dim3(512), dim3(256), 0, stream, f);
-        hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, f);
-        hipLaunchKernelGGL(k_tile_bin<true>, dim3(512), dim3(256), 0, stream, f);
+        hipLaunchKernelGGL(k_tile_fill, dim3(512), dim3(256), ((n_tiles + 1u) & ~1u) * 4u + 256u * 8u, stream, f);
         hipLaunchKernelGGL(k_tile_raster<kTileBlock>, dim3(f.grid.deferred_blocks), dim3((kTilePart / kTileBlock) * (kTilePart / kTileBlock)), 0, stream, sv, f);
     };
     if (sv.draw_count && !fv.occlusion) {
