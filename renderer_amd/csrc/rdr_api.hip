@@ -521,7 +521,6 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
     if (const char* e = std::getenv("RDR_LANE_MAX_PIXELS")) r->lane_max_pixels = (uint32_t)std::min(4096, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("RDR_MID_MAX_PIXELS")) r->mid_max_pixels = (uint32_t)std::min(4096, std::max(1, std::atoi(e)));
     RDR_HIP(hipSetDevice(r->device));
-    if (rdr_geometry_residency(&r->resident)) return 1;
     RDR_HIP(hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking));
     r->stream = r->own_stream;
     if (r->cfg.time_kernels) {
@@ -540,7 +539,8 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
         RDR_HIP(hipMemset(r->tile_count.ptr, 0, 2 * n_tiles * 4));
         RDR_HIP(hipMemset(r->tile_cursor.ptr, 0, n_tiles * 4)); // k_tile_fill expects it zero; k_tile_raster leaves it so
         // k_tile_fill keeps one bin offset per tile in LDS (64 KiB: 15 872 tiles, e.g. 11 264 x 5 760 pixels)
-        RDR_CHECK(n_tiles * 4 + 2056 <= 65536, "rdr_create: frame too large for the tile path (more than 15 872 tiles of 64 x 64 pixels)");
+        RDR_CHECK(rdr_tile_fill_lds((uint32_t)n_tiles) <= 65536, "rdr_create: frame too large for the tile path (more than 15 872 tiles of 64 x 64 pixels)");
+        if (rdr_geometry_residency(&r->resident, rdr_tile_fill_lds((uint32_t)n_tiles))) return 1;
     }
     RDR_HIP(hipMemset(r->counters.ptr, 0, 2 * sizeof(FrameCounters)));
     {

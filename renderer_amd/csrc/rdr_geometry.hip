@@ -903,7 +903,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : 1
 // Mid-sized triangles queued by k_raster: one wave per record, every lane one pixel of each
 // 8x8 stamp, fragments merged with the same atomic as the per-lane scan.  Spreads the pixel
 // work of a meshlet that covers a lot of screen over many waves.
-__global__ __launch_bounds__(256) void k_mid_raster(SceneView sv, FrameView fv) {
+RDR_DEV void mid_raster_role(const SceneView& sv, const FrameView& fv, uint32_t block, uint32_t n_blocks) {
     __shared__ uint32_t wg_frags[4];
     const uint32_t lane = lane_id();
     // the queue is segmented (FrameCounters::mid_seg): lane s holds the running total up to segment s
@@ -911,7 +911,7 @@ __global__ __launch_bounds__(256) void k_mid_raster(SceneView sv, FrameView fv) 
     const uint32_t seg_n = lane < kMidSegments ? min(fv.counters->mid_seg[lane * 32u], seg_capacity) : 0u;
     const uint32_t seg_end = wave_scan_inclusive(seg_n, lane);
     const uint32_t count = __shfl(seg_end, 63, 64);
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t wave = (block * blockDim.x + threadIdx.x) >> 6, n_waves = (n_blocks * blockDim.x) >> 6;
     uint32_t frags = 0;
     for (uint32_t i = wave; i < count; i += n_waves) {
         const uint32_t seg = (uint32_t)__popcll(__ballot(lane < kMidSegments && seg_end <= i)); // segments that end at or before i
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(256) void k_mid_raster(SceneView sv, FrameView fv) 
         const uint32_t f = wave_sum(frags);
         if (lane == 0) wg_frags[threadIdx.x >> 6] = f;
         __syncthreads();
-        if (threadIdx.x == 0) stat_store(fv, fv.grid.slot_mid + blockIdx.x, wg_frags[0] + wg_frags[1] + wg_frags[2] + wg_frags[3]);
+        if (threadIdx.x == 0) stat_store(fv, fv.grid.slot_mid + block, wg_frags[0] + wg_frags[1] + wg_frags[2] + wg_frags[3]);
     }
 }
 
@@ -1280,12 +1280,12 @@ __global__ __launch_bounds__(64) void k_tile_setup(SceneView sv, FrameView fv) {
 // entries in the low 40 bits, jobs above.  Then the records are visited as in count_tiles and written into
 // their tiles' bins.  FrameView::tile_cursor is zero on entry (k_tile_raster leaves it so).
 constexpr uint32_t kBinChunk = 4;
-__global__ __launch_bounds__(256) void k_tile_fill(FrameView fv) {
+RDR_DEV void tile_fill_role(const FrameView& fv, uint32_t block, uint32_t n_blocks) {
     extern __shared__ uint32_t tile_off[]; // n_tiles offsets, then the scan's 256 partial sums (64-bit)
     const uint32_t lane = lane_id();
     const uint32_t count = min(fv.counters->setup_count, fv.setup_capacity);
     if (count == 0u) { // nothing was set up: empty bins, no jobs
-        if (blockIdx.x == 0 && threadIdx.x == 0) { fv.counters->bin_total = 0u; fv.counters->tile_nonempty = 0u; }
+        if (block == 0 && threadIdx.x == 0) { fv.counters->bin_total = 0u; fv.counters->tile_nonempty = 0u; }
         return;
     }
     const uint32_t n_tiles = fv.tiles_x * fv.tiles_y;
@@ -1308,7 +1308,7 @@ __global__ __launch_bounds__(256) void k_tile_fill(FrameView fv) {
         }
         const unsigned long long before = partial[threadIdx.x] - sum;
         uint32_t run = (uint32_t)(before & ((1ull << 40) - 1ull)), listed = (uint32_t)(before >> 40);
-        const bool writer = threadIdx.x % gridDim.x == blockIdx.x; // this thread's tiles go to memory from this workgroup
+        const bool writer = threadIdx.x % n_blocks == block; // this thread's tiles go to memory from this workgroup
         for (uint32_t i = first; i < last; ++i) {
             const uint32_t c = fv.tile_count[i];
             tile_off[i] = run;
@@ -1320,7 +1320,7 @@ __global__ __launch_bounds__(256) void k_tile_fill(FrameView fv) {
             }
             run += c;
         }
-        if (blockIdx.x == 0 && threadIdx.x == 255u) {
+        if (block == 0 && threadIdx.x == 255u) {
             const unsigned long long total = partial[255] & ((1ull << 40) - 1ull);
             fv.counters->bin_total = (uint32_t)min(total, 0xFFFFFFFFull);
             fv.counters->tile_nonempty = (uint32_t)min(partial[255] >> 40, (unsigned long long)fv.tile_list_capacity);
@@ -1331,7 +1331,7 @@ __global__ __launch_bounds__(256) void k_tile_fill(FrameView fv) {
     // A wave takes kBinChunk records at a time, not 64: records that cover many tiles are walked by
     // the whole wave one after another, and a frame usually has few records but some very wide ones
     // (walls, floors), so small chunks spread those over many more waves.
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t wave = (block * blockDim.x + threadIdx.x) >> 6, n_waves = (n_blocks * blockDim.x) >> 6;
     for (uint32_t base_i = wave * kBinChunk; base_i < count; base_i += n_waves * kBinChunk) {
         const uint32_t i = base_i + lane;
         uint32_t tx0 = 0, ty0 = 0, tw = 1, nt = 0;
@@ -1383,6 +1383,16 @@ __global__ __launch_bounds__(256) void k_tile_fill(FrameView fv) {
     }
 }
 
+// The two consumers of k_tile_setup's output in one launch, because neither needs the other: the first
+// kFillBlocks workgroups fill the bins (first, so that they are running when the rest of the grid, a whole
+// resident round, takes the machine), the other FrameView::grid.mid_blocks scan the mid-sized triangles.
+// One dependent launch less (4-5 us when both have nothing to do), and where both have work it overlaps.
+constexpr uint32_t kFillBlocks = 512;
+__global__ __launch_bounds__(256) void k_mid_fill(SceneView sv, FrameView fv) {
+    if (blockIdx.x < kFillBlocks) tile_fill_role(fv, blockIdx.x, kFillBlocks);
+    else mid_raster_role(sv, fv, blockIdx.x - kFillBlocks, fv.grid.mid_blocks);
+}
+
 // A workgroup takes jobs: kTileJob records of one tile's bin over one kTilePart x kTilePart piece of the
 // tile, a thread owning B x B pixels of it.  Small jobs in a one-resident-round grid, because what a tile
 // costs is mostly the chain of dependent loads in front of the arithmetic (list -> count / offset -> bin ->
@@ -1405,7 +1415,7 @@ __global__ __launch_bounds__((kTilePart / B) * (kTilePart / B)) void k_tile_rast
             if (w < n_words) reinterpret_cast<uint32_t*>(fv.counters_next)[w] = 0u;
             else {
                 fv.tile_count_next[w - n_words] = 0u;
-                fv.tile_cursor[w - n_words] = 0u; // k_tile_fill is done with it and expects it zero the next time
+                fv.tile_cursor[w - n_words] = 0u; // k_mid_fill is done with it and expects it zero the next time
             }
         }
     }
@@ -1715,7 +1725,7 @@ __global__ __launch_bounds__(256) void k_resolve(SceneView sv, FrameView fv, uin
 
 // Workgroups of each persistent kernel that are resident at once on the current device:
 // their grids are sized to exactly one resident round, so no workgroup waits for a slot.
-int rdr_geometry_residency(GeometryResidency* out) {
+int rdr_geometry_residency(GeometryResidency* out, uint32_t fill_lds_bytes) {
     int device = 0, cus = 0, n = 0;
     RDR_HIP(hipGetDevice(&device));
     RDR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
@@ -1729,7 +1739,7 @@ int rdr_geometry_residency(GeometryResidency* out) {
     out->raster_touch = (uint32_t)(n * cus);
     RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (k_raster<true, true>), 64, 0));
     out->raster_mask_touch = (uint32_t)(n * cus);
-    RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mid_raster, 256, 0));
+    RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mid_fill, 256, fill_lds_bytes));
     out->mid_raster = (uint32_t)(n * cus);
     RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_alpha_frag, 256, 0));
     out->alpha_frag = (uint32_t)(n * cus);
@@ -1764,9 +1774,8 @@ int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t st
             hipLaunchKernelGGL(k_alpha_frag, dim3(f.grid.frag_blocks), dim3(256), 0, stream, sv, f);
         }
         hipLaunchKernelGGL(k_tile_setup, dim3(1024), dim3(64), 0, stream, sv, f); // also feeds k_mid_raster
-        hipLaunchKernelGGL(k_mid_raster, dim3(f.grid.mid_blocks), dim3(256), 0, stream, sv, f);
+        hipLaunchKernelGGL(k_mid_fill, dim3(f.grid.mid_blocks + kFillBlocks), dim3(256), rdr_tile_fill_lds(n_tiles), stream, sv, f);
         if (mid_event) (void)hipEventRecord(*mid_event, stream);
-        hipLaunchKernelGGL(k_tile_fill, dim3(512), dim3(256), ((n_tiles + 1u) & ~1u) * 4u + 256u * 8u, stream, f);
         hipLaunchKernelGGL(k_tile_raster<kTileBlock>, dim3(f.grid.deferred_blocks), dim3((kTilePart / kTileBlock) * (kTilePart / kTileBlock)), 0, stream, sv, f);
     };
     if (sv.draw_count && !fv.occlusion) {

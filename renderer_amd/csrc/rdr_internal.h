@@ -390,7 +390,9 @@ struct GeometryResidency {
     uint32_t meshlet_cull, raster, raster_mask, mid_raster, alpha_frag, tile_raster; // resident workgroups on the whole device
     uint32_t raster_touch, raster_mask_touch; // k_raster's instantiations that keep the sort-last tile flags
 };
-int rdr_geometry_residency(GeometryResidency* out);
+int rdr_geometry_residency(GeometryResidency* out, uint32_t fill_lds_bytes);
+// Dynamic LDS of k_mid_fill: one bin offset per 64x64 tile and the 256 partial sums of its prefix sum.
+inline uint32_t rdr_tile_fill_lds(uint32_t n_tiles) { return ((n_tiles + 1u) & ~1u) * 4u + 256u * 8u; }
 int rdr_launch_shadow(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev); // classify + shadow rays
 int rdr_launch_shade(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev);  // the above, then k_shade
 // ---- peer-to-peer sort-last exchange (rdr_composite.hip) ----------------------------
