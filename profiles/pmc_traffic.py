@@ -36,7 +36,7 @@ for k, c in acc.items():
 # the bench's "raster" bracket holds both instantiations and the mid-size pass
 merged = defaultdict(int)
 for k, v in kernels.items():
-    name = "raster" if k.startswith("raster<") or k == "mid_raster" else k.split("<")[0]  # template instantiations together
+    name = "raster" if k.startswith("raster<") or k == "mid_fill" else k.split("<")[0]  # template instantiations together
     merged[name] += v
 issue_acc = defaultdict(lambda: defaultdict(list))
 for sub in ("sq3", "tcp"):
@@ -44,7 +44,8 @@ for sub in ("sq3", "tcp"):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
             if k.startswith("k_"):
-                name = k[2:].split("<")[0] if not k.startswith("k_raster<") else k[2:]
+                # the opaque instantiation stands for the bench's "raster" bracket, the others keep their full names
+                name = k[2:].split("<")[0] if not k.startswith("k_raster<") else ("raster" if k.startswith("k_raster<false") else k[2:])
                 issue_acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 issue = {}
 for k, c in sorted(issue_acc.items()):
@@ -59,7 +60,7 @@ out = {
     "workload": workload,
     "note": "HBM bytes per launch from rocprofv3 PMC passes (profiles/pmc_passes.sh fetch, write): "
             "(2*FETCH_SIZE + WRITE_SIZE) KiB; FETCH_SIZE doubled for gfx950's 64-B tally of 128-B reads; "
-            "raster = k_raster<false> + k_raster<true> + k_mid_raster",
+            "raster = the k_raster instantiations + k_mid_fill",
     "kernels": dict(sorted(merged.items())),
     "issue_note": "valu_busy = SQ_INSTS_VALU * 2 cycles (SIMD-32: one wave64 instruction per 2 cycles) / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs); "
                   "lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_INSTS_VALU) (passes sq3, tcp)",
