@@ -11,15 +11,14 @@
 // through HIP IPC handles, one process per GPU.
 //
 // Ordering between ranks is by monotonic phase numbers in a small control block per renderer: a rank
-// tells every peer "I have reached phase n" by storing n into its own slot of the peer's block
-// (k_signal), and waits by polling its own block until every slot has reached n (k_wait).  Per frame f:
-//   3f+1  my keys are complete            (peers may read my visibility buffer)
-//   3f+2  I have finished reading yours   (after k_composite_min)
-//   3f+3  my colour rows are in your image (after k_push_color)
-// A rank waits for 3f+1 before reading keys and for 3f+3 at the end of the frame; the latter also tells
-// it that every peer is past 3f+2, so clearing the visibility buffer for the next frame is safe.  Every
-// wait is bounded (about five seconds of wall clock): a peer that never arrives turns into an error
-// flag, not a hang.
+// tells every peer "I have reached phase n" by storing n into its own slot of the peer's block and
+// waits by polling its own block until every slot has reached n (k_signal_wait does both).  Per frame f:
+//   2f+1  my keys are complete             (peers may read my visibility buffer)
+//   2f+2  my colour tiles are in your image (after k_push_tiles, which comes after this rank read the keys)
+// A rank waits for 2f+1 before reading keys and for 2f+2 at the end of the frame; the latter also tells
+// it that every peer has finished reading its keys (a peer pushes after it has read), so clearing the
+// visibility buffer for the next frame is safe.  Every wait is bounded (about five seconds of wall
+// clock): a peer that never arrives turns into an error flag, not a hang.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -38,18 +37,14 @@ struct PeerTable {
     uint32_t* ctrl[RDR_COMPOSITE_MAX_RANKS];
 };
 
-// Phase `phase` reached: written into this rank's slot of every peer's control block.  The data the
-// phase stands for was written by earlier kernels of this stream, which have completed.
-__global__ void k_signal(PeerTable peers, uint32_t rank, uint32_t world, uint32_t phase) {
-    const uint32_t p = threadIdx.x;
-    if (p < world && p != rank) __hip_atomic_store(&peers.ctrl[p][rank], phase, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// Waits until every peer's slot in this rank's control block has reached `phase`; gives up after
-// kWaitTicks and records that in *timed_out (pinned host memory).
-__global__ void k_wait(const uint32_t* ctrl, uint32_t rank, uint32_t world, uint32_t phase, uint32_t* timed_out) {
+// Phase `phase` reached: written into this rank's slot of every peer's control block (the data the phase stands
+// for was written by earlier kernels of this stream, which have completed); then wait until every peer's slot in
+// this rank's block has reached the same phase.  One lane per peer.  The wait gives up after kWaitTicks and records
+// that in *timed_out (pinned host memory).
+__global__ void k_signal_wait(PeerTable peers, const uint32_t* ctrl, uint32_t rank, uint32_t world, uint32_t phase, uint32_t* timed_out) {
     const uint32_t p = threadIdx.x;
     if (p >= world || p == rank) return;
+    __hip_atomic_store(&peers.ctrl[p][rank], phase, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     const long long start = wall_clock64();
     for (;;) {
         const uint32_t seen = __hip_atomic_load(&ctrl[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -308,15 +303,13 @@ int rdr_composite_check(rdr_composite_state* c, const char* who) {
 int rdr_composite_launch_exchange(rdr_composite_state* c, uint32_t row_lo, uint32_t row_hi, hipStream_t stream) {
     RDR_CHECK(c->connected, "rdr_composite_exchange: not connected");
     c->frame++;
-    const uint32_t base = 3u * c->frame;
-    hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, stream, c->peers, c->rank, c->world, base + 1u);
-    hipLaunchKernelGGL(k_wait, dim3(1), dim3(64), 0, stream, c->ctrl, c->rank, c->world, base + 1u, c->timed_out_dev);
+    const uint32_t base = 2u * c->frame;
+    hipLaunchKernelGGL(k_signal_wait, dim3(1), dim3(64), 0, stream, c->peers, c->ctrl, c->rank, c->world, base + 1u, c->timed_out_dev);
     if (row_hi > row_lo) {
         dim3 grid;
         const TileGrid g = tile_grid(c, row_lo, row_hi, grid);
         hipLaunchKernelGGL(k_composite_tiles, grid, dim3(256), 0, stream, c->peers, c->rank, c->world, g, c->union_now, c->use_flags ? 1u : 0u);
     }
-    hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, stream, c->peers, c->rank, c->world, base + 2u);
     RDR_HIP(hipGetLastError());
     return 0;
 }
@@ -325,7 +318,7 @@ int rdr_composite_launch_exchange(rdr_composite_state* c, uint32_t row_lo, uint3
 int rdr_composite_launch_gather(rdr_composite_state* c, uint32_t row_lo, uint32_t row_hi, bool every_tile, hipStream_t stream) {
     RDR_CHECK(c->connected, "rdr_composite_gather: not connected");
     RDR_CHECK(c->frame > 0, "rdr_composite_gather: no exchange has run for this frame");
-    const uint32_t base = 3u * c->frame;
+    const uint32_t base = 2u * c->frame;
     if (row_hi > row_lo) {
         if (row_lo != c->pushed_lo || row_hi != c->pushed_hi) {
             // a new strip: what the peers' images hold in it is unknown, so every tile counts as written before
@@ -337,8 +330,7 @@ int rdr_composite_launch_gather(rdr_composite_state* c, uint32_t row_lo, uint32_
         hipLaunchKernelGGL(k_push_tiles, grid, dim3(256), 0, stream, c->peers, c->rank, c->world, g, c->union_now, c->union_prev,
                            (every_tile || !c->use_flags) ? 1u : 0u);
     }
-    hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, stream, c->peers, c->rank, c->world, base + 3u);
-    hipLaunchKernelGGL(k_wait, dim3(1), dim3(64), 0, stream, c->ctrl, c->rank, c->world, base + 3u, c->timed_out_dev);
+    hipLaunchKernelGGL(k_signal_wait, dim3(1), dim3(64), 0, stream, c->peers, c->ctrl, c->rank, c->world, base + 2u, c->timed_out_dev);
     RDR_HIP(hipGetLastError());
     return 0;
 }
