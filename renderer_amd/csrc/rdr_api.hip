@@ -66,6 +66,7 @@ struct rdr_renderer {
     uint64_t frames_started = 0; // frames since the last rdr_get_stats
     int cur_slot = 0;
     bool frame_rendered = false, shaded = false;
+    bool force_tile_flags = false; // measurement hook RDR_TILE_FLAGS=1: keep the flags without an exchange
     bool frame_has_tile_flags = false; // the visibility buffer on the device was rendered with FrameView::touched kept
     bool timing_this_frame = false;
 
@@ -351,7 +352,7 @@ FrameView make_frame_view(rdr_renderer* r) {
     FrameView fv{};
     fv.ubo = r->ubo;
     fv.vis = r->vis.ptr;
-    const bool flags = rdr_composite_connected(r->composite);
+    const bool flags = rdr_composite_connected(r->composite) || r->force_tile_flags;
     fv.touched = flags ? reinterpret_cast<uint32_t*>(r->vis.ptr + (size_t)r->width * r->height) : nullptr;
     fv.touched_x = (r->width + kTouchTile - 1) / kTouchTile;
     fv.touched_count = rdr_touched_words(r->width, r->height);
@@ -552,6 +553,7 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
         RDR_HIP(hipHostGetDevicePointer(&dev, host, 0));
         r->status_dev = static_cast<uint32_t*>(dev);
     }
+    if (const char* e = std::getenv("RDR_TILE_FLAGS")) r->force_tile_flags = std::atoi(e) != 0;
     if (const char* e = std::getenv("RDR_CONVEX_SKIP")) r->convex_skip = std::atoi(e) != 0 ? 1u : 0u;
     if (const char* e = std::getenv("RDR_DEBUG_DEFERRED_CAPACITY")) // test hook: force the deferred list to overflow
         r->debug_deferred_capacity = (uint32_t)std::max(1, std::atoi(e));

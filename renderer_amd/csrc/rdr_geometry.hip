@@ -382,21 +382,29 @@ RDR_DEV void touch_pixel(const FrameView& fv, int px, int py) {
 // a wave per SIMD): every tile under the pixel box of the meshlet's vertices that need no clipping.  Triangles
 // scanned by a lane have three such vertices, so their pixels lie inside; the others go to kernels that mark
 // for themselves.  (X, Y): the lane's snapped 24.8 vertex, `valid`: it has one.
+// Wave-wide minimum as a scalar: four butterfly steps inside each row of 16 lanes on the data-parallel
+// path (no LDS round trips, one temporary), then the four rows through scalar registers.
+RDR_DEV int32_t wave_min_scalar(int32_t v) {
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false)); // row_half_mirror
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false)); // row_mirror
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
 RDR_DEV void touch_meshlet(const FrameView& fv, bool valid, int32_t X, int32_t Y, uint32_t lane) {
-    int32_t x0 = valid ? X : 0x7FFFFFFF, y0 = valid ? Y : 0x7FFFFFFF, x1 = valid ? X : -0x7FFFFFFF, y1 = valid ? Y : -0x7FFFFFFF;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        x0 = min(x0, __shfl_xor(x0, o, 64)); y0 = min(y0, __shfl_xor(y0, o, 64));
-        x1 = max(x1, __shfl_xor(x1, o, 64)); y1 = max(y1, __shfl_xor(y1, o, 64));
-    }
+    const int32_t big = 0x7FFFFFFF;
+    const int32_t x0 = wave_min_scalar(valid ? X : big), y0 = wave_min_scalar(valid ? Y : big);
+    const int32_t x1 = -wave_min_scalar(valid ? -X : big), y1 = -wave_min_scalar(valid ? -Y : big);
     if (x0 > x1) return; // no usable vertex
     // a pixel box never reaches past floor(min / 256) .. floor(max / 256) (setup_triangle rounds inwards)
     const int32_t px0 = max(x0 >> 8, 0), py0 = max(y0 >> 8, 0);
     const int32_t px1 = min(x1 >> 8, (int32_t)fv.width - 1), py1 = min(y1 >> 8, (int32_t)fv.height - 1);
     if (px0 > px1 || py0 > py1) return;
-    const uint32_t tx0 = (uint32_t)px0 / kTouchTile, ty0 = (uint32_t)py0 / kTouchTile;
-    const uint32_t nx = (uint32_t)px1 / kTouchTile - tx0 + 1u, n = nx * ((uint32_t)py1 / kTouchTile - ty0 + 1u);
-    for (uint32_t i = lane; i < n; i += 64u) fv.touched[(ty0 + i / nx) * fv.touched_x + tx0 + i % nx] = 1u;
+    const uint32_t tx1 = (uint32_t)px1 / kTouchTile, ty1 = (uint32_t)py1 / kTouchTile;
+    for (uint32_t ty = (uint32_t)py0 / kTouchTile; ty <= ty1; ++ty) // rows: the same in every lane; columns: a lane each
+        for (uint32_t tx = (uint32_t)px0 / kTouchTile + lane; tx <= tx1; tx += 64u) fv.touched[ty * fv.touched_x + tx] = 1u;
 }
 
 RDR_DEV void emit_fragment(const FrameView& fv, int px, int py, float z, uint32_t id) {
@@ -605,7 +613,7 @@ struct MaskVertexLds<true> {
 // TOUCH: keep the sort-last tile flags (an instantiation of its own: the few registers the marking needs would
 // cost the plain opaque one its fifth wave per SIMD).
 template <bool MASK, bool TOUCH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : 1))) void k_raster(SceneView sv, FrameView fv) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : (TOUCH ? 5 : 1)))) void k_raster(SceneView sv, FrameView fv) {
     __shared__ MeshletLds lds;
     __shared__ MaskVertexLds<MASK> mlds;
     const uint32_t lane = threadIdx.x;
