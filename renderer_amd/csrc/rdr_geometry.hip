@@ -393,11 +393,14 @@ RDR_DEV int32_t wave_min_scalar(int32_t v) {
                min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
-RDR_DEV void touch_meshlet(const FrameView& fv, bool valid, int32_t X, int32_t Y, uint32_t lane) {
+RDR_DEV void touch_meshlet(const FrameView& fv, bool valid, const int32_t* lds_x, const int32_t* lds_y, uint32_t lane) {
     const int32_t big = 0x7FFFFFFF;
-    const int32_t x0 = wave_min_scalar(valid ? X : big), y0 = wave_min_scalar(valid ? Y : big);
-    const int32_t x1 = -wave_min_scalar(valid ? -X : big), y1 = -wave_min_scalar(valid ? -Y : big);
+    // one coordinate at a time: what is live here decides whether the kernel keeps its fifth wave per SIMD
+    int32_t v = lds_x[lane];
+    const int32_t x0 = wave_min_scalar(valid ? v : big), x1 = -wave_min_scalar(valid ? -v : big);
     if (x0 > x1) return; // no usable vertex
+    v = lds_y[lane];
+    const int32_t y0 = wave_min_scalar(valid ? v : big), y1 = -wave_min_scalar(valid ? -v : big);
     // a pixel box never reaches past floor(min / 256) .. floor(max / 256) (setup_triangle rounds inwards)
     const int32_t px0 = max(x0 >> 8, 0), py0 = max(y0 >> 8, 0);
     const int32_t px1 = min(x1 >> 8, (int32_t)fv.width - 1), py1 = min(y1 >> 8, (int32_t)fv.height - 1);
@@ -679,9 +682,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : (
             }
         }
         __syncthreads();
+        if (TOUCH) touch_meshlet(fv, lane < m.vertex_count && lds.clip[lane] == 0u, lds.X, lds.Y, lane);
         if (has_next && lane < (vm_next.counts & 0xFFFFu)) // in flight during the triangle phase
             vi_next = sv.meshlet_vertices[vm_next.vertex_offset + lane] + vm_next.mesh_vertex_offset;
-        if (TOUCH) touch_meshlet(fv, lane < m.vertex_count && lds.clip[lane] == 0u, lds.X[lane], lds.Y[lane], lane);
 
         // Triangle phase 1: the mesh shader's cull tests, two triangles per lane; the survivors (about
         // four in ten on a closed mesh) are packed into an LDS queue so that phase 2 runs on full lanes.
