@@ -33,7 +33,7 @@ def main():
     rank, world, d = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     device = int(os.environ.get("P2P_DEVICE", "0"))
     scene = synth.make_field(60, 3, lods=1, alpha_fraction=0.3, with_env=True, prepared=True)
-    conf = RendererConfig(cull_enabled=False, skybox=os.environ.get("P2P_SKYBOX") == "1")
+    conf = RendererConfig(cull_enabled=os.environ.get("P2P_OCCLUSION") == "1", skybox=os.environ.get("P2P_SKYBOX") == "1")
     r = Renderer(W, H, conf, device=device)
     r.set_scene(scene)
     r.set_partition(*instance_range(scene.meshlet_visibility_count, rank, world))
