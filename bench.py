@@ -334,6 +334,13 @@ def main():
                                f"{len(frame.slots)} frames in flight" + ("" if args.backend == "nccl" else " [gloo rehearsal]"),
             },
             "kernel_ms": {k: round(v, 4) for k, v in kms.items() if v > 0},
+            # the brackets tile the frame (each spans its group of launches, dependency latency included) and are taken on
+            # every 8th frame, which they lengthen by about 33 us: the difference to ms_per_step is that and the host's gaps
+            "kernel_ms_sum": round(sum(kms.values()), 4),
+            "frame_minus_kernels_ms": round(ms - sum(kms.values()), 4),
+            "launches_per_frame": {"all_opaque_no_occlusion": 10, "with_alpha_tested_draws": 12,
+                                   "note": "dependent kernel launches of one frame on this path (draw cull, meshlet cull, raster, tile set-up, "
+                                           "mid + fill, tile raster, classify, shadow, deep shadow, shade; alpha-tested draws add two)"},
             "frame_counters": {k: st[k] for k in ("draws_visible", "meshlets_tested", "meshlets_visible",
                                                   "triangles_submitted", "triangles_tested", "triangles_rasterised",
                                                   "fragments", "pixels_covered", "vertices_transformed")},
