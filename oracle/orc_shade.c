@@ -21,7 +21,7 @@
  * Choices where the Vulkan implementation has latitude: texture(brdf_lut) and
  * texture(lambertian) use LOD 0 (their implicit LOD depends on quad
  * derivatives); pow(x, 5) and pow(x, 2) are exact products; the ray/triangle
- * test is a division-free Moeller-Trumbore in object space with the instance
+ * test is watertight (as the ray query is), in object space with the instance
  * transform inverted in double precision; a ray hits when tmin < t < tmax.
  */
 #include <stdlib.h>
@@ -128,22 +128,41 @@ static int ray_box(const float* lo, const float* hi, const float* o, const float
     return 1;
 }
 
-/* Moeller-Trumbore without the division, two-sided, open interval (tmin, tmax):
- * with a = |det| and the numerators multiplied by sign(det), the ray hits when
- * U >= 0, V >= 0, U + V <= a and tmin * a < T < tmax * a. */
+/* Ray / triangle, two-sided, open interval (tmin, tmax), watertight: the Vulkan ray query the reference uses
+ * guarantees that a ray through an edge or a vertex shared by triangles hits at least one of them, so a closed
+ * mesh has no cracks for a ray to slip through.  The test is the one of Woop, Benthin and Wald ("Watertight
+ * Ray/Triangle Intersection", 2013): the triangle is moved to the ray's origin and sheared so that the ray runs
+ * along the axis of its largest direction component; the three edge functions of the projected triangle are
+ * then differences of products of the same two vertices whichever of the two triangles at an edge computes
+ * them, hence agree in sign, and an edge function that comes out exactly zero is recomputed in double
+ * precision.  t = T / det is compared without the division.  (Both faces count, so the paper's swap of
+ * the two other axes for a negative direction component, which only keeps the winding, is left out.) */
+static float v3_get(v3 a, int k) { return k == 0 ? a.x : (k == 1 ? a.y : a.z); }
 static int ray_triangle(v3 o, v3 d, v3 p0, v3 p1, v3 p2, float tmin, float tmax) {
-    v3 e1 = v3_sub(p1, p0), e2 = v3_sub(p2, p0);
-    v3 pv = v3_cross(d, e2);
-    float det = v3_dot(e1, pv);
+    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    int kz = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+    int kx = kz == 2 ? 0 : kz + 1, ky = kx == 2 ? 0 : kx + 1;
+    float dz = v3_get(d, kz);
+    float Sx = v3_get(d, kx) / dz, Sy = v3_get(d, ky) / dz, Sz = 1.0f / dz;
+    v3 A = v3_sub(p0, o), B = v3_sub(p1, o), C = v3_sub(p2, o);
+    float Akz = v3_get(A, kz), Bkz = v3_get(B, kz), Ckz = v3_get(C, kz);
+    float Ax = v3_get(A, kx) - Sx * Akz, Ay = v3_get(A, ky) - Sy * Akz;
+    float Bx = v3_get(B, kx) - Sx * Bkz, By = v3_get(B, ky) - Sy * Bkz;
+    float Cx = v3_get(C, kx) - Sx * Ckz, Cy = v3_get(C, ky) - Sy * Ckz;
+    float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
+    if (U == 0.0f || V == 0.0f || W == 0.0f) {
+        U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+        V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+        W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+    }
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return 0;
+    float det = (U + V) + W;
     if (det == 0.0f) return 0;
-    v3 tv = v3_sub(o, p0);
-    float un = v3_dot(tv, pv);
-    v3 qv = v3_cross(tv, e1);
-    float vn = v3_dot(d, qv);
-    float tn = v3_dot(e2, qv);
+    float Az = Sz * Akz, Bz = Sz * Bkz, Cz = Sz * Ckz;
+    float T = (U * Az + V * Bz) + W * Cz;
     float sgn = det < 0.0f ? -1.0f : 1.0f;
-    float a = fabsf(det), U = un * sgn, V = vn * sgn, T = tn * sgn;
-    return U >= 0.0f && V >= 0.0f && U + V <= a && T > tmin * a && T < tmax * a;
+    float a = fabsf(det), Ts = T * sgn;
+    return Ts > tmin * a && Ts < tmax * a;
 }
 
 typedef struct {

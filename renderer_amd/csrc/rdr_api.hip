@@ -114,6 +114,7 @@ struct rdr_renderer {
     DeviceBuffer<uint32_t> tlas_items;
     DeviceBuffer<float> blas_tris;
     DeviceBuffer<GpuInstance> instances;
+    DeviceBuffer<float4> instance_ball;
 
     // host copies needed to rebuild the TLAS when transforms change
     std::vector<rdr_mesh_draw> h_draws;
@@ -138,7 +139,7 @@ struct rdr_renderer {
     uint32_t seen_status[2] = {0, 0};
     uint32_t debug_deferred_capacity = 0xFFFFFFFFu; // test hook: smaller deferred list
     rdr_composite_state* composite = nullptr; // peer-to-peer sort-last exchange, created on first use
-    uint32_t convex_skip = 1; // measurement hook RDR_CONVEX_SKIP=0: trace every shadow ray through its own instance
+    uint32_t convex_skip = 1; // measurement hook RDR_CONVEX_SKIP=0: trace every shadow ray through its own instance; bit 1: inner-ball shortcut
 };
 
 namespace {
@@ -341,10 +342,14 @@ int upload_tlas(rdr_renderer* r) {
     RDR_HIP(hipMemcpy(r->bvh_dev.ptr + blas_count, r->bvh.tlas_pairs.data(), r->bvh.tlas_pairs.size() * sizeof(BvhWide), hipMemcpyHostToDevice));
     if (r->tlas_items.upload(r->bvh.tlas_items.data(), r->bvh.tlas_items.size())) return 1;
     if (r->instances.upload(r->bvh.instances.data(), r->bvh.instances.size())) return 1;
+    if (const char* e = std::getenv("RDR_INNER_BALL")) // measurement hook: 0 = no instance has an inner ball
+        if (std::atoi(e) == 0) std::fill(r->bvh.instance_ball.begin(), r->bvh.instance_ball.end(), 0.0f);
+    if (r->instance_ball.upload(reinterpret_cast<const float4*>(r->bvh.instance_ball.data()), r->bvh.instance_ball.size() / 4)) return 1;
     r->sv.bvh = r->bvh_dev.ptr;
     r->sv.tlas_base = (uint32_t)blas_count;
     r->sv.tlas_items = r->tlas_items.ptr;
     r->sv.instances = r->instances.ptr;
+    r->sv.instance_ball = r->instance_ball.ptr;
     return 0;
 }
 

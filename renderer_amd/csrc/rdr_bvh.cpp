@@ -289,6 +289,10 @@ void affine_inverse(const float* m, float* out12) {
 struct Convexity {
     int8_t sign = 0;
     float protrusion = 0.0f;
+    // a ball inside the body and one around it, about the centre of its bounding box: every face plane at least
+    // r_in away from the centre (0 when the centre is not inside), every vertex within r_out
+    float centre[3] = {0.0f, 0.0f, 0.0f};
+    float r_in = 0.0f, r_out = 0.0f;
 };
 
 uint64_t fnv1a(const void* data, size_t n, uint64_t h) {
@@ -352,6 +356,10 @@ Convexity analyse_convexity(const rdr_scene_desc& s, uint32_t mi) {
     }
     const double extent = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
     const double tol = 1e-5 * extent;
+    const double ctr[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
+    double r_out = 0.0, face_near = 1e300, face_far = -1e300; // signed distances of the face planes from the centre
+    for (size_t v = 0; v < nv; ++v)
+        r_out = std::max(r_out, std::sqrt((px[v] - ctr[0]) * (px[v] - ctr[0]) + (py[v] - ctr[1]) * (py[v] - ctr[1]) + (pz[v] - ctr[2]) * (pz[v] - ctr[2])));
     double above = 0.0, below = 0.0; // largest distance of a vertex in front of / behind a face plane
     for (uint32_t t = 0; t < ntri; ++t) {
         const uint32_t a = tri[3 * (size_t)t], b = tri[3 * (size_t)t + 1], c = tri[3 * (size_t)t + 2];
@@ -361,6 +369,9 @@ Convexity analyse_convexity(const rdr_scene_desc& s, uint32_t mi) {
         if (!(len > 0.0)) return none;
         n[0] /= len; n[1] /= len; n[2] /= len;
         const double d0 = n[0] * px[a] + n[1] * py[a] + n[2] * pz[a];
+        const double dc = d0 - (n[0] * ctr[0] + n[1] * ctr[1] + n[2] * ctr[2]);
+        face_near = std::min(face_near, dc);
+        face_far = std::max(face_far, dc);
         double mx = -1e300, mn = 1e300;
         for (size_t v = 0; v < nv; ++v) {
             const double d = n[0] * px[v] + n[1] * py[v] + n[2] * pz[v];
@@ -374,6 +385,12 @@ Convexity analyse_convexity(const rdr_scene_desc& s, uint32_t mi) {
     Convexity out;
     if (above <= tol) { out.sign = 1; out.protrusion = (float)above; }
     else { out.sign = -1; out.protrusion = (float)below; }
+    for (int k = 0; k < 3; ++k) out.centre[k] = (float)ctr[k];
+    out.r_out = (float)(r_out * 1.0001);
+    // normals point outwards for sign +1 (every plane in front of the centre), inwards for -1; the deviation from
+    // exact convexity is taken off
+    const double r_in = (out.sign > 0 ? face_near : -face_far) - 2.0 * (double)out.protrusion - tol;
+    out.r_in = r_in > 0.0 ? (float)r_in : 0.0f;
     return out;
 }
 
@@ -411,6 +428,7 @@ void rdr_build_blas(const rdr_scene_desc& s, HostBvh& out) {
     out.mesh_tri_base.assign(s.mesh_count, 0);
     out.mesh_convex_sign.assign(s.mesh_count, 0);
     out.mesh_protrusion.assign(s.mesh_count, 0.0f);
+    out.mesh_ball.assign(5 * (size_t)s.mesh_count, 0.0f);
     std::vector<BvhNode> nodes;
     std::vector<Item> items;
     for (uint32_t mi = 0; mi < s.mesh_count; ++mi) {
@@ -438,18 +456,33 @@ void rdr_build_blas(const rdr_scene_desc& s, HostBvh& out) {
             const Convexity cx = mesh_convexity(s, mi);
             out.mesh_convex_sign[mi] = cx.sign;
             out.mesh_protrusion[mi] = cx.protrusion;
+            // every mesh: a ball around it (centre of the root box, farthest LOD-0 vertex, 0.01 % slack); closed convex
+            // ones: a ball inside it as well (see GpuInstance::outer_radius)
+            const BvhNode& rb = nodes[0];
+            if (ntri && rb.lo[0] <= rb.hi[0]) {
+                double c[3], far2 = 0.0;
+                for (int k = 0; k < 3; ++k) c[k] = 0.5 * ((double)rb.lo[k] + (double)rb.hi[k]);
+                if (cx.sign != 0 && cx.r_in > 0.0f)
+                    for (int k = 0; k < 3; ++k) c[k] = cx.centre[k];
+                for (uint32_t i = 0; i < 3 * ntri; ++i) {
+                    const float* p = s.vertices[s.indices[mesh.index_offset + i] + mesh.vertex_offset].p;
+                    far2 = std::max(far2, (p[0] - c[0]) * (p[0] - c[0]) + (p[1] - c[1]) * (p[1] - c[1]) + (p[2] - c[2]) * (p[2] - c[2]));
+                }
+                for (int k = 0; k < 3; ++k) out.mesh_ball[5 * (size_t)mi + k] = (float)c[k];
+                out.mesh_ball[5 * (size_t)mi + 3] = (cx.sign != 0 && cx.r_in > 0.0f) ? 0.999f * cx.r_in : 0.0f;
+                out.mesh_ball[5 * (size_t)mi + 4] = (float)(std::sqrt(far2) * 1.0001 + 1e-30);
+            }
         }
         out.mesh_root[mi] = (uint32_t)out.blas_pairs.size();
         out.mesh_tri_base[mi] = (uint32_t)(out.blas_tris.size() / 9);
         out.mesh_bounds[mi] = nodes[0];
         flatten(nodes, out.blas_pairs);
         for (uint32_t t = 0; t < ntri; ++t) {
-            // stored as p0, e1 = p1 - p0, e2 = p2 - p0 (single-precision differences)
+            // stored as its three vertices
             const float* p[3];
             for (int k = 0; k < 3; ++k) p[k] = s.vertices[s.indices[mesh.index_offset + 3 * items[t].index + k] + mesh.vertex_offset].p;
-            for (int c = 0; c < 3; ++c) out.blas_tris.push_back(p[0][c]);
-            for (int c = 0; c < 3; ++c) out.blas_tris.push_back(p[1][c] - p[0][c]);
-            for (int c = 0; c < 3; ++c) out.blas_tris.push_back(p[2][c] - p[0][c]);
+            for (int v = 0; v < 3; ++v)
+                for (int c = 0; c < 3; ++c) out.blas_tris.push_back(p[v][c]);
         }
     }
 }
@@ -457,6 +490,7 @@ void rdr_build_blas(const rdr_scene_desc& s, HostBvh& out) {
 void rdr_build_tlas(const rdr_scene_desc& s, const float* transforms, HostBvh& io) {
     std::vector<Item> items(s.draw_count);
     io.instances.resize(s.draw_count);
+    io.instance_ball.assign(4 * (size_t)s.draw_count, 0.0f);
     for (uint32_t di = 0; di < s.draw_count; ++di) {
         const rdr_mesh_draw& d = s.mesh_draws[di];
         const float* m = transforms + (size_t)d.model_index * 16;
@@ -464,8 +498,9 @@ void rdr_build_tlas(const rdr_scene_desc& s, const float* transforms, HostBvh& i
         affine_inverse(m, inst.inv);
         inst.blas_root = io.mesh_root[d.mesh_index];
         inst.tri_base = io.mesh_tri_base[d.mesh_index];
-        inst._pad = 0;
+        inst.outer_radius = io.mesh_ball[5 * (size_t)d.mesh_index + 4];
         inst.convex_cos = 0.0f;
+        for (int k = 0; k < 4; ++k) io.instance_ball[4 * (size_t)di + k] = io.mesh_ball[5 * (size_t)d.mesh_index + k];
         const BvhNode& root = io.mesh_bounds[d.mesh_index];
         Item& it = items[di];
         it.box.reset();

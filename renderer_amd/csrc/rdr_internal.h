@@ -255,7 +255,12 @@ struct GpuInstance {
     // the triangle tests, and the mesh's deviation from exact convexity), and the sign tells which way the
     // world-space cross product (w2 - w1) x (w3 - w1) of a face points (+ outwards, - inwards).
     float convex_cos;
-    uint32_t _pad;
+    // Every mesh lies within outer_radius of a centre (SceneView::instance_ball.xyz, object space; 0 = unknown): a ray
+    // meets the instance only between the parameters at which it enters and leaves that ball.  A closed mesh around a
+    // convex body also contains a ball about the same centre (instance_ball.w, 0 = none): a ray that is inside it at a
+    // parameter beyond tmin is inside the body there and outside it before tmax, so it crosses the surface in
+    // between, and the ray / triangle test is watertight: some triangle is hit.  Such a ray is blocked without a walk.
+    float outer_radius;
 };
 
 // Everything the kernels read, passed by value.
@@ -273,6 +278,7 @@ struct SceneView {
     const rdr_material* materials;
     const float* transforms;
     const uint32_t* instance_draw; // meshlet instance -> draw id
+    const float4* instance_ball;   // per draw: see GpuInstance::outer_radius
     uint8_t* draw_lod;             // per frame: LOD each draw selected, 0xFF = not drawn
     const GpuImage* images;
     const uint8_t* texels;
@@ -377,6 +383,8 @@ struct HostBvh {
     std::vector<uint32_t> mesh_tri_base; // per mesh
     std::vector<int8_t> mesh_convex_sign;   // per mesh: 0 not a closed convex surface, +1 / -1 face winding outwards / inwards
     std::vector<float> mesh_protrusion;     // per mesh: how far a vertex lies outside a face plane at most (object units)
+    std::vector<float> mesh_ball;           // per mesh: centre, inner radius (0: none), outer radius (GpuInstance::outer_radius)
+    std::vector<float> instance_ball;       // per instance: centre and inner radius, for the kernels
     std::vector<BvhNode> tlas_nodes;
     std::vector<uint32_t> tlas_items;
     std::vector<GpuInstance> instances;

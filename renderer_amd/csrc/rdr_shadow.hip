@@ -43,24 +43,52 @@ RDR_DEV bool ray_box(uint32_t wx, uint32_t wy, uint32_t wz, const SlabRay& r, fl
     return t_in <= t_out;
 }
 
-// Moeller-Trumbore without the division, two-sided, open interval (tmin, tmax): with
-// a = |det| and the numerators multiplied by sign(det), the ray hits when
-// U >= 0, V >= 0, U + V <= a and tmin * a < T < tmax * a.  e1 = p1 - p0 and
-// e2 = p2 - p0 are stored with the triangle.
-RDR_DEV bool ray_triangle(vec3 o, vec3 d, vec3 p0, vec3 e1, vec3 e2, float tmin, float tmax) {
-    const vec3 pv = cross3(d, e2);
-    const float det = dot3(e1, pv);
-    const vec3 tv = o - p0;
-    const float un = dot3(tv, pv);
-    const vec3 qv = cross3(tv, e1);
-    const float vn = dot3(d, qv);
-    const float tn = dot3(e2, qv);
-    const uint32_t sign = __float_as_uint(det) & 0x80000000u;
-    const float a = fabsf(det);
-    const float U = __uint_as_float(__float_as_uint(un) ^ sign);
-    const float V = __uint_as_float(__float_as_uint(vn) ^ sign);
-    const float T = __uint_as_float(__float_as_uint(tn) ^ sign);
-    return det != 0.0f && U >= 0.0f && V >= 0.0f && U + V <= a && T > tmin * a && T < tmax * a;
+// Ray / triangle, two-sided, open interval (tmin, tmax), watertight like the ray query it stands for: a ray
+// through an edge or a vertex shared by triangles hits at least one of them.  Woop, Benthin and Wald's test
+// ("Watertight Ray/Triangle Intersection", 2013): the triangle is moved to the ray's origin and sheared so that
+// the ray runs along the axis of its largest direction component; the three edge functions of the projected
+// triangle are differences of products of the same two vertices whichever triangle at an edge computes them, so
+// their signs agree, and one that comes out exactly zero is recomputed in double precision.  t = T / det is
+// compared without the division.  Both faces count, so the paper's swap of the two other axes for a negative
+// direction component (it only keeps the winding) is left out.  The same operations in the same order as the
+// CPU check.
+// The ray's part of it is computed once per ray (Shear, below): the axis, the two shear factors, the
+// reciprocal, and the origin with its components already rotated so that the ray's axis comes last.
+struct Shear {
+    int kz;          // axis of the largest direction component
+    float sx, sy, sz; // d[kx] / d[kz], d[ky] / d[kz], 1 / d[kz] with (kx, ky, kz) a cyclic rotation of (x, y, z)
+    vec3 o;          // the origin as (o[kx], o[ky], o[kz])
+};
+RDR_DEV vec3 rotate_axes(vec3 a, int kz) { // (a[kx], a[ky], a[kz])
+    return kz == 0 ? mk3(a.y, a.z, a.x) : (kz == 1 ? mk3(a.z, a.x, a.y) : a);
+}
+RDR_DEV Shear make_shear(vec3 o, vec3 d) {
+    Shear s;
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    s.kz = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+    const vec3 r = rotate_axes(d, s.kz);
+    s.sx = r.x / r.z; s.sy = r.y / r.z; s.sz = 1.0f / r.z;
+    s.o = rotate_axes(o, s.kz);
+    return s;
+}
+RDR_DEV bool ray_triangle(const Shear& s, vec3 p0, vec3 p1, vec3 p2, float tmin, float tmax) {
+    const vec3 A = rotate_axes(p0, s.kz) - s.o, B = rotate_axes(p1, s.kz) - s.o, C = rotate_axes(p2, s.kz) - s.o;
+    const float Ax = A.x - s.sx * A.z, Ay = A.y - s.sy * A.z;
+    const float Bx = B.x - s.sx * B.z, By = B.y - s.sy * B.z;
+    const float Cx = C.x - s.sx * C.z, Cy = C.y - s.sy * C.z;
+    float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
+    if (U == 0.0f || V == 0.0f || W == 0.0f) {
+        U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+        V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+        W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+    }
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+    const float det = (U + V) + W;
+    if (det == 0.0f) return false;
+    const float Az = s.sz * A.z, Bz = s.sz * B.z, Cz = s.sz * C.z;
+    const float T = (U * Az + V * Bz) + W * Cz;
+    const float a = fabsf(det), Ts = det < 0.0f ? -T : T;
+    return Ts > tmin * a && Ts < tmax * a;
 }
 
 // Traversal stacks.  The fast one keeps kLdsStack entries per lane in LDS (one
@@ -103,6 +131,7 @@ struct DeepStack {
 struct Ray {
     vec3 o, d;
     SlabRay slab;
+    Shear shear; // for the triangle tests: only rays in an instance's object space meet triangles
 };
 
 // Margin per axis: |c| * 2^-24 (rounding of c) plus (2^-23 + 2^-24) * |t| for the
@@ -132,7 +161,37 @@ RDR_DEV Ray object_ray(const GpuInstance& inst, vec3 o, vec3 d, float tmax) {
                         ((iv[8] * o.x + iv[9] * o.y) + iv[10] * o.z) + iv[11]);
     const vec3 od = mk3((iv[0] * d.x + iv[1] * d.y) + iv[2] * d.z, (iv[4] * d.x + iv[5] * d.y) + iv[6] * d.z,
                         (iv[8] * d.x + iv[9] * d.y) + iv[10] * d.z);
-    return make_ray(oo, od, tmax);
+    Ray r = make_ray(oo, od, tmax);
+    r.shear = make_shear(oo, od);
+    return r;
+}
+
+// What an instance's two balls (GpuInstance::outer_radius) say about a ray in its object space (o, d):
+//   kBallBlocked  the ray is inside the inner ball somewhere beyond tmin and leaves the outer one before tmax: it is
+//                 blocked, no walk needed;
+//   kBallMissed   the ray does not come within the outer ball between tmin and tmax: the instance cannot block it;
+//   kBallWalk     walk the instance, and nothing beyond t_hi (where the ray leaves the outer ball) can be hit.
+// The radii carry their own slack (0.1 % inside, 0.01 % outside) and the parameters another 1 %, far more than
+// rounding moves anything here.
+enum BallVerdict { kBallWalk, kBallBlocked, kBallMissed };
+RDR_DEV BallVerdict ball_verdict(float4 ball, float outer_radius, vec3 o, vec3 d, float tmin, float tmax, float& t_hi) {
+    t_hi = tmax;
+    if (!(outer_radius > 0.0f)) return kBallWalk;
+    const vec3 oc = mk3(o.x - ball.x, o.y - ball.y, o.z - ball.z);
+    const float a = dot3(d, d), b = dot3(oc, d), cc = dot3(oc, oc);
+    if (!(a > 0.0f)) return kBallWalk;
+    const float disc_out = b * b - a * (cc - outer_radius * outer_radius);
+    if (disc_out < 0.0f) return kBallMissed;
+    const float root_out = sqrtf(disc_out);
+    const float t_leave_out = (root_out - b) / a, t_enter_out = (-root_out - b) / a;
+    if (t_leave_out * 1.01f + 1e-30f < tmin || t_enter_out * 0.99f - 1e-30f > tmax) return kBallMissed;
+    if (t_leave_out >= 0.0f) t_hi = fminf(tmax, t_leave_out * 1.01f + 1e-30f);
+    const float disc_in = b * b - a * (cc - ball.w * ball.w);
+    if (ball.w > 0.0f && disc_in > 0.0f) {
+        const float t_leave_in = (sqrtf(disc_in) - b) / a;
+        if (t_leave_in > tmin * 1.01f && t_leave_out < tmax * 0.99f) return kBallBlocked;
+    }
+    return kBallWalk;
 }
 
 // Is anything between the surface point and the sun?  One loop walks both levels: `cur` is
@@ -156,6 +215,11 @@ RDR_DEV bool shadow_any_hit(const SceneView& sv, uint32_t own_instance, bool ski
     uint32_t node_base = skip_own ? sv.tlas_base : sv.instances[own_instance].blas_root, tri_base = sv.instances[own_instance].tri_base;
     uint32_t cur = 0u;
     bool hit = false;
+    float t_hi = tmax; // the walk's far limit inside the current instance
+    if (!skip_own) {
+        const BallVerdict v = ball_verdict(sv.instance_ball[own_instance], sv.instances[own_instance].outer_radius, ray.o, ray.d, tmin, tmax, t_hi);
+        if (v == kBallBlocked) return true;
+    }
     for (;;) {
         if (!(cur & kBvhLeaf)) {
             // one wide node: all its loads are in flight together
@@ -172,7 +236,7 @@ RDR_DEV bool shadow_any_hit(const SceneView& sv, uint32_t own_instance, bool ski
 #pragma unroll
             for (int i = 0; i < kBvhWidth; ++i) {
                 float t_exit;
-                const bool h = (code[i] != kBvhNone) & ray_box(wx[i], wy[i], wz[i], ray.slab, tmin, tmax, t_exit);
+                const bool h = (code[i] != kBvhNone) & ray_box(wx[i], wy[i], wz[i], ray.slab, tmin, t_hi, t_exit);
                 const bool take = h & (t_exit >= cur_exit);
                 st.push_if(h & (cur != kBvhNone), take ? cur : code[i]);
                 cur = take ? code[i] : cur;
@@ -187,7 +251,7 @@ RDR_DEV bool shadow_any_hit(const SceneView& sv, uint32_t own_instance, bool ski
                 const float* tp = sv.blas_tris + (size_t)(tri_base + first) * 9;
 #pragma clang loop vectorize(disable)
                 for (uint32_t i = 0; i < count; ++i, tp += 9)
-                    hit |= ray_triangle(ray.o, ray.d, mk3(tp[0], tp[1], tp[2]), mk3(tp[3], tp[4], tp[5]), mk3(tp[6], tp[7], tp[8]), tmin, tmax);
+                    hit |= ray_triangle(ray.shear, mk3(tp[0], tp[1], tp[2]), mk3(tp[3], tp[4], tp[5]), mk3(tp[6], tp[7], tp[8]), tmin, t_hi);
             } else {
                 // top-level leaf: take its first instance now, leave the others on the stack
                 const uint32_t instance = sv.tlas_items[first];
@@ -195,16 +259,19 @@ RDR_DEV bool shadow_any_hit(const SceneView& sv, uint32_t own_instance, bool ski
                 if (instance != own_instance) {
                     const GpuInstance& inst = sv.instances[instance];
                     ray = object_ray(inst, o, d, tmax);
+                    const BallVerdict v = ball_verdict(sv.instance_ball[instance], inst.outer_radius, ray.o, ray.d, tmin, tmax, t_hi);
+                    hit = v == kBallBlocked;
                     node_base = inst.blas_root;
                     tri_base = inst.tri_base;
                     floor = st.sp;
-                    cur = 0u;
+                    cur = v == kBallMissed ? kBvhNone : 0u; // a missed instance is exhausted at once
                 }
             }
         }
         if (hit) break;
         if (cur == kBvhNone) {
             if (st.sp == floor) { // this instance is done: back to the world ray
+                t_hi = tmax;
                 floor = -1;
                 ray = make_ray(o, d, tmax);
                 node_base = sv.tlas_base;
