@@ -139,6 +139,7 @@ struct rdr_renderer {
     uint32_t seen_status[2] = {0, 0};
     uint32_t debug_deferred_capacity = 0xFFFFFFFFu; // test hook: smaller deferred list
     rdr_composite_state* composite = nullptr; // peer-to-peer sort-last exchange, created on first use
+    uint32_t shadow_defer = 1; // measurement hook RDR_SHADOW_DEFER=0: own-instance walks stay inside k_shadow
     uint32_t convex_skip = 1; // measurement hook RDR_CONVEX_SKIP=0: trace every shadow ray through its own instance; bit 1: inner-ball shortcut
 };
 
@@ -385,6 +386,7 @@ FrameView make_frame_view(rdr_renderer* r) {
     fv.pixel_list = r->pixel_list.ptr;
     fv.lds_stack_limit = r->lds_stack_limit;
     fv.convex_skip = r->convex_skip;
+    fv.shadow_defer = r->shadow_defer;
     fv.host_status = r->status_dev;
     fv.frame_seq = r->frame_seq & 0xFFFFFFu;
     fv.deferred_capacity = std::min(fv.deferred_capacity, r->debug_deferred_capacity);
@@ -535,7 +537,7 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
     }
     const size_t npx = (size_t)width * height;
     // the sort-last tile flags (FrameView::touched) live behind the keys, in the allocation the peers open
-    if (r->vis.alloc(npx + (rdr_touched_words(width, height) + 1) / 2) || r->color.alloc(npx * 4) || r->counters.alloc(2) || r->shadow.alloc(npx) ||
+    if (r->vis.alloc(npx + (rdr_touched_words(width, height) + 1) / 2) || r->color.alloc(npx * 4) || r->counters.alloc(2) || r->shadow.alloc((npx + 15) / 16 * 16) ||
         r->pixel_list.alloc(npx)) return 1;
     // depth pyramid: W/2 x H/2 and its mips, a little over a third of a pixel count
     if (r->pyramid.alloc(npx / 2 + width + height + 64)) return 1; // sum over levels <= W*H/3 + W + H + levels
@@ -560,6 +562,7 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
     }
     if (const char* e = std::getenv("RDR_TILE_FLAGS")) r->force_tile_flags = std::atoi(e) != 0;
     if (const char* e = std::getenv("RDR_CONVEX_SKIP")) r->convex_skip = std::atoi(e) != 0 ? 1u : 0u;
+    if (const char* e = std::getenv("RDR_SHADOW_DEFER")) r->shadow_defer = std::atoi(e) != 0 ? 1u : 0u; // measurement hook
     if (const char* e = std::getenv("RDR_DEBUG_DEFERRED_CAPACITY")) // test hook: force the deferred list to overflow
         r->debug_deferred_capacity = (uint32_t)std::max(1, std::atoi(e));
     float lut[256];

@@ -469,7 +469,13 @@ void rdr_build_blas(const rdr_scene_desc& s, HostBvh& out) {
                     far2 = std::max(far2, (p[0] - c[0]) * (p[0] - c[0]) + (p[1] - c[1]) * (p[1] - c[1]) + (p[2] - c[2]) * (p[2] - c[2]));
                 }
                 for (int k = 0; k < 3; ++k) out.mesh_ball[5 * (size_t)mi + k] = (float)c[k];
-                out.mesh_ball[5 * (size_t)mi + 3] = (cx.sign != 0 && cx.r_in > 0.0f) ? 0.999f * cx.r_in : 0.0f;
+                // inner radius: what the ball test's own rounding can move (a few units in the last place of the
+                // largest coordinate it handles, and the centre's rounding to single precision) taken off thirty
+                // times over; every 0.01 % given away here widens the band of grazing rays that have to be walked
+                double cmax = 0.0;
+                for (int k = 0; k < 3; ++k) cmax = std::max(cmax, std::fabs(c[k]));
+                const double r_in = (cx.sign != 0 && cx.r_in > 0.0f) ? (double)cx.r_in * (1.0 - 3e-5) - 2.4e-7 * (cmax + std::sqrt(far2)) : 0.0;
+                out.mesh_ball[5 * (size_t)mi + 3] = r_in > 0.0 ? (float)r_in : 0.0f;
                 out.mesh_ball[5 * (size_t)mi + 4] = (float)(std::sqrt(far2) * 1.0001 + 1e-30);
             }
         }

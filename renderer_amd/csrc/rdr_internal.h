@@ -108,7 +108,7 @@ struct FrameCounters {
     uint32_t deferred_count;
     uint32_t deferred_overflow;
     uint32_t pixel_count;     // covered pixels in the shaded rows (length of pixel_list)
-    uint32_t shadow_overflow; // pixels k_shadow left to k_shadow_deep (must follow pixel_count)
+    uint32_t shadow_overflow; // rays that overflowed k_shadow's LDS stack, left to k_shadow_walk (must follow pixel_count)
     uint32_t setup_count;     // SetupTri records written this frame
     uint32_t setup_overflow;
     uint32_t bin_total;       // tile-bin entries needed this frame
@@ -321,7 +321,7 @@ struct FrameView {
     uint32_t command_capacity, visible_capacity, deferred_capacity;
     uint32_t collect_stats;
     uint32_t* pixel_list; // indices of the covered pixels in the shaded rows (k_classify)
-    uint8_t* shadow;      // one byte per pixel_list entry: 1 = the sun ray is blocked
+    uint8_t* shadow;      // one byte per pixel_list entry: 1 = the sun ray is blocked (padded to a multiple of 16 bytes)
     SetupTri* setup;
     SetupMask* setup_mask;
     uint32_t* tile_count;  // per tile: triangles binned
@@ -367,6 +367,7 @@ struct FrameView {
     uint32_t* host_status;
     uint32_t frame_seq;
     uint32_t convex_skip; // 1: shadow rays that leave a closed convex mesh skip that mesh (0 only as a measurement hook)
+    uint32_t shadow_defer; // 1: walks through a ray's own closed convex instance are left to k_shadow_walk (0 only as a measurement hook)
     // Per-workgroup statistics: every workgroup stores its partial counts in its own
     // slot with plain stores (no contended atomics); the host sums the slots on request.
     uint32_t* stat_slots;

@@ -171,7 +171,7 @@ RDR_DEV Ray object_ray(const GpuInstance& inst, vec3 o, vec3 d, float tmax) {
 //                 blocked, no walk needed;
 //   kBallMissed   the ray does not come within the outer ball between tmin and tmax: the instance cannot block it;
 //   kBallWalk     walk the instance, and nothing beyond t_hi (where the ray leaves the outer ball) can be hit.
-// The radii carry their own slack (0.1 % inside, 0.01 % outside) and the parameters another 1 %, far more than
+// The radii carry their own slack (0.003 % inside, 0.01 % outside) and the parameters another 1 %, far more than
 // rounding moves anything here.
 enum BallVerdict { kBallWalk, kBallBlocked, kBallMissed };
 RDR_DEV BallVerdict ball_verdict(float4 ball, float outer_radius, vec3 o, vec3 d, float tmin, float tmax, float& t_hi) {
@@ -205,21 +205,45 @@ RDR_DEV BallVerdict ball_verdict(float4 ball, float outer_radius, vec3 o, vec3 d
 // `skip_own`: the caller has established that the ray cannot meet the pixel's own instance (it leaves
 // a closed convex mesh outwards): the walk starts in the state in which that instance's bottom level
 // has just been exhausted.
+// `mode` says which part of the work this call does (the parts' results OR together, in any order):
+//   kTraceAll    everything;
+//   kTraceDefer  everything, except that the walk through the own instance is left out, and reported in
+//                `deferred`, when that instance has an inner ball (a closed convex mesh): what is left of
+//                those after the ball tests are the rays that graze the mesh near its terminator, a few
+//                per cent of the rays with a dozen and more steps each through the leaves under the surface,
+//                and in a wave of rays that are done after the set-up they would keep the wave alive for
+//                their own sake.  k_shadow_walk takes them packed into full waves;
+//   kTraceOwn    the walk through the own instance alone.
+enum TraceMode : uint32_t { kTraceAll = 0, kTraceDefer = 1, kTraceOwn = 2 };
+
 template <typename Stack>
-RDR_DEV bool shadow_any_hit(const SceneView& sv, uint32_t own_instance, bool skip_own, vec3 o, vec3 d, float tmin, float tmax, Stack& st) {
+RDR_DEV bool shadow_any_hit(const SceneView& sv, uint32_t own_instance, bool skip_own, vec3 o, vec3 d, float tmin, float tmax, Stack& st,
+                            uint32_t mode, bool& deferred) {
     st.sp = 0;
     st.overflow = false;
-    if (!skip_own) st.push(0u); // node 0 of a tree holds the children of its root
-    int floor = skip_own ? -1 : 1;
-    Ray ray = skip_own ? make_ray(o, d, tmax) : object_ray(sv.instances[own_instance], o, d, tmax);
-    uint32_t node_base = skip_own ? sv.tlas_base : sv.instances[own_instance].blas_root, tri_base = sv.instances[own_instance].tri_base;
+    deferred = false;
+    bool walk_own = !skip_own;
+    float t_hi = tmax; // the walk's far limit inside the current instance
+    Ray ray;
+    if (walk_own) {
+        ray = object_ray(sv.instances[own_instance], o, d, tmax);
+        const float4 ball = sv.instance_ball[own_instance];
+        const BallVerdict v = ball_verdict(ball, sv.instances[own_instance].outer_radius, ray.o, ray.d, tmin, tmax, t_hi);
+        if (v == kBallBlocked) return true;
+        if (v == kBallMissed) walk_own = false; // the ray is out of the instance's reach before tmin
+        else if (mode == kTraceDefer && ball.w > 0.0f) { walk_own = false; deferred = true; }
+    }
+    if (mode == kTraceOwn && !walk_own) return false;
+    if (!walk_own) {
+        ray = make_ray(o, d, tmax);
+        t_hi = tmax;
+    } else {
+        st.push(0u); // node 0 of a tree holds the children of its root
+    }
+    int floor = walk_own ? 1 : -1;
+    uint32_t node_base = walk_own ? sv.instances[own_instance].blas_root : sv.tlas_base, tri_base = sv.instances[own_instance].tri_base;
     uint32_t cur = 0u;
     bool hit = false;
-    float t_hi = tmax; // the walk's far limit inside the current instance
-    if (!skip_own) {
-        const BallVerdict v = ball_verdict(sv.instance_ball[own_instance], sv.instances[own_instance].outer_radius, ray.o, ray.d, tmin, tmax, t_hi);
-        if (v == kBallBlocked) return true;
-    }
     for (;;) {
         if (!(cur & kBvhLeaf)) {
             // one wide node: all its loads are in flight together
@@ -271,6 +295,7 @@ RDR_DEV bool shadow_any_hit(const SceneView& sv, uint32_t own_instance, bool ski
         if (hit) break;
         if (cur == kBvhNone) {
             if (st.sp == floor) { // this instance is done: back to the world ray
+                if (mode == kTraceOwn) break;
                 t_hi = tmax;
                 floor = -1;
                 ray = make_ray(o, d, tmax);
@@ -381,44 +406,91 @@ __global__ __launch_bounds__(1024) void k_classify(FrameView fv) {
 
 // Pass 1: the sun shadow ray of every covered pixel (shading.frag.glsl:421-425), kept
 // apart from the material evaluation so that the pointer-chasing traversal runs at
-// high occupancy with its stack in LDS.  The result is stored per list entry.
+// high occupancy with its stack in LDS.  The result is stored per list entry:
+// 0 lit, 1 blocked, and two codes that k_shadow_walk resolves to 0 or 1.
+constexpr uint8_t kShadowLit = 0, kShadowBlocked = 1, kShadowRetrace = 2, kShadowWalkOwn = 3;
+
+struct ShadowRay {
+    uint32_t draw_id;
+    bool skip_own;
+    vec3 o, d;
+};
+RDR_DEV ShadowRay shadow_ray_of(const SceneView& sv, const FrameView& fv, uint32_t entry) {
+    const ListedPixel p = listed_pixel(sv, fv, entry);
+    vec3 face_normal;
+    ShadowRay r;
+    r.o = pixel_world_position(sv, fv.ubo, p.draw_id, p.meshlet, p.tri, p.uvx, p.uvy, face_normal);
+    r.d = normalize3(mk3(fv.ubo.sun_direction[0], fv.ubo.sun_direction[1], fv.ubo.sun_direction[2]));
+    r.draw_id = p.draw_id;
+    r.skip_own = (fv.convex_skip & 1u) && leaves_convex_mesh(sv, p.draw_id, face_normal, r.d);
+    return r;
+}
+constexpr float kShadowTmin = 1e-2f, kShadowTmax = 1000.0f;
+
 __global__ __launch_bounds__(256) void k_shadow(SceneView sv, FrameView fv) {
     __shared__ uint32_t stack_mem[(kLdsStack + 1) * 256];
     const uint32_t entry = blockIdx.x * 256u + threadIdx.x;
     if (entry >= fv.counters->pixel_count) return;
-    const ListedPixel p = listed_pixel(sv, fv, entry);
-    vec3 face_normal;
-    const vec3 w_pos = pixel_world_position(sv, fv.ubo, p.draw_id, p.meshlet, p.tri, p.uvx, p.uvy, face_normal);
-    const rdr_ubo& u = fv.ubo;
-    const vec3 L = normalize3(mk3(u.sun_direction[0], u.sun_direction[1], u.sun_direction[2]));
+    const ShadowRay r = shadow_ray_of(sv, fv, entry);
     LdsStack st;
     st.base = stack_mem + threadIdx.x;
     st.limit = (int)fv.lds_stack_limit;
-    const bool h = shadow_any_hit(sv, p.draw_id, fv.convex_skip && leaves_convex_mesh(sv, p.draw_id, face_normal, L), w_pos, L, 1e-2f, 1000.0f, st);
-    uint8_t hit = h ? 1 : 0;
-    if (!h && st.overflow) { // a miss that dropped stack entries proves nothing: leave it to k_shadow_deep
-        hit = 2;
+    bool deferred;
+    const bool h = shadow_any_hit(sv, r.draw_id, r.skip_own, r.o, r.d, kShadowTmin, kShadowTmax, st, fv.shadow_defer ? kTraceDefer : kTraceAll, deferred);
+    uint8_t code = h ? kShadowBlocked : (deferred ? kShadowWalkOwn : kShadowLit);
+    if (!h && st.overflow) { // a miss that dropped stack entries proves nothing: traced again with the deep stack
+        code = kShadowRetrace;
         atomicAdd(&fv.counters->shadow_overflow, 1u);
     }
-    fv.shadow[entry] = hit;
+    fv.shadow[entry] = code;
 }
 
-// Pass 1b: pixels whose traversal overflowed the LDS stack, traced again with the deep
-// scratch-backed stack.  Exits at once when there are none (the normal case).
-__global__ __launch_bounds__(256) void k_shadow_deep(SceneView sv, FrameView fv) {
-    if (fv.counters->shadow_overflow == 0u) return;
+// Pass 1b: the rays k_shadow left open.  A workgroup reads the result bytes of kWalkChunk consecutive list
+// entries (sixteen per thread), collects the entries with an open code in LDS and traces those with full
+// waves: the deferred walks through the ray's own closed convex instance with the LDS stack, and, with the
+// deep scratch-backed stack, whatever overflowed the LDS stack (in k_shadow or here).  The two kinds are
+// rare and evenly spread over the list, so every workgroup has about the same little to do.
+constexpr uint32_t kWalkChunk = 4096;
+
+__global__ __launch_bounds__(256) void k_shadow_walk(SceneView sv, FrameView fv) {
+    __shared__ uint32_t stack_mem[(kLdsStack + 1) * 256];
+    __shared__ uint32_t open_list[kWalkChunk];
+    __shared__ uint32_t open_count;
     const uint32_t count = fv.counters->pixel_count;
-    const rdr_ubo& u = fv.ubo;
-    for (uint32_t entry = blockIdx.x * blockDim.x + threadIdx.x; entry < count; entry += gridDim.x * blockDim.x) {
-        if (fv.shadow[entry] != 2) continue;
-        const ListedPixel p = listed_pixel(sv, fv, entry);
-        vec3 face_normal;
-        const vec3 w_pos = pixel_world_position(sv, u, p.draw_id, p.meshlet, p.tri, p.uvx, p.uvy, face_normal);
-        const vec3 L = normalize3(mk3(u.sun_direction[0], u.sun_direction[1], u.sun_direction[2]));
-        DeepStack st;
-        const bool h = shadow_any_hit(sv, p.draw_id, fv.convex_skip && leaves_convex_mesh(sv, p.draw_id, face_normal, L), w_pos, L, 1e-2f, 1000.0f, st);
-        if (!h && st.overflow) atomicAdd(&fv.counters->deep_overflow, 1u); // a miss that dropped entries proves nothing: reported
-        fv.shadow[entry] = h ? 1 : 0;
+    const uint32_t chunk0 = blockIdx.x * kWalkChunk;
+    if (chunk0 >= count) return;
+    if (threadIdx.x == 0) open_count = 0u;
+    __syncthreads();
+    const uint32_t e0 = chunk0 + threadIdx.x * 16u;
+    if (e0 < count) { // the buffer is padded to a multiple of 16 bytes; entries past the list's end hold older frames' bytes
+        const uint4 q = *reinterpret_cast<const uint4*>(fv.shadow + e0);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; ++k) {
+            const uint32_t code = (w[k >> 2] >> ((k & 3u) * 8u)) & 0xFFu;
+            if (code >= kShadowRetrace && e0 + k < count) open_list[atomicAdd(&open_count, 1u)] = ((e0 + k) << 2) | code;
+        }
+    }
+    __syncthreads();
+    const uint32_t n = open_count;
+    for (uint32_t i = threadIdx.x; i < n; i += 256u) {
+        const uint32_t entry = open_list[i] >> 2;
+        uint32_t code = open_list[i] & 3u;
+        const ShadowRay r = shadow_ray_of(sv, fv, entry);
+        bool deferred, h = false;
+        if (code == kShadowWalkOwn) {
+            LdsStack st;
+            st.base = stack_mem + threadIdx.x;
+            st.limit = (int)fv.lds_stack_limit;
+            h = shadow_any_hit(sv, r.draw_id, r.skip_own, r.o, r.d, kShadowTmin, kShadowTmax, st, kTraceOwn, deferred);
+            code = (!h && st.overflow) ? kShadowRetrace + 4u : 0u; // 6: the own instance once more, with the deep stack
+        }
+        if (code != 0u) {
+            DeepStack st;
+            h = shadow_any_hit(sv, r.draw_id, r.skip_own, r.o, r.d, kShadowTmin, kShadowTmax, st, code == kShadowRetrace ? kTraceAll : kTraceOwn, deferred);
+            if (!h && st.overflow) atomicAdd(&fv.counters->deep_overflow, 1u); // a miss that dropped entries proves nothing: reported
+        }
+        fv.shadow[entry] = h ? kShadowBlocked : kShadowLit;
     }
 }
 
@@ -437,7 +509,7 @@ int rdr_launch_shadow(const SceneView& sv, const FrameView& fv, hipStream_t stre
     hipLaunchKernelGGL(k_classify, tiles, dim3(1024), 0, stream, fv);
     if (ev) RDR_HIP(hipEventRecord(ev[7], stream));
     hipLaunchKernelGGL(k_shadow, dim3(list_blocks), dim3(256), 0, stream, sv, fv);
-    hipLaunchKernelGGL(k_shadow_deep, dim3(512), dim3(256), 0, stream, sv, fv);
+    hipLaunchKernelGGL(k_shadow_walk, dim3((list_blocks * 256u + kWalkChunk - 1u) / kWalkChunk), dim3(256), 0, stream, sv, fv);
     if (ev) RDR_HIP(hipEventRecord(ev[8], stream));
     RDR_HIP(hipGetLastError());
     return 0;
