@@ -87,6 +87,7 @@ struct rdr_renderer {
     DeviceBuffer<float> srgb_lut;
     DeviceBuffer<uint8_t> shadow;
     DeviceBuffer<uint32_t> pixel_list;
+    DeviceBuffer<uint32_t> pixel_key;
     DeviceBuffer<FragTri> frag_tri;
     DeviceBuffer<uint32_t> frag_px;
     DeviceBuffer<uint32_t> stat_slots;
@@ -104,6 +105,8 @@ struct rdr_renderer {
     DeviceBuffer<float> transforms;
     DeviceBuffer<uint32_t> instance_draw;
     DeviceBuffer<uint8_t> draw_lod;
+    DeviceBuffer<DrawFrame> draw_frame;
+    DeviceBuffer<TriVertices> tri_table;
     DeviceBuffer<uint8_t> draw_visible;
     DeviceBuffer<uint32_t> meshlet_bits;
     DeviceBuffer<uint32_t> pyramid;
@@ -384,6 +387,7 @@ FrameView make_frame_view(rdr_renderer* r) {
     fv.collect_stats = r->cfg.collect_stats;
     fv.shadow = r->shadow.ptr;
     fv.pixel_list = r->pixel_list.ptr;
+    fv.pixel_key = r->pixel_key.ptr;
     fv.lds_stack_limit = r->lds_stack_limit;
     fv.convex_skip = r->convex_skip;
     fv.shadow_defer = r->shadow_defer;
@@ -538,7 +542,7 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
     const size_t npx = (size_t)width * height;
     // the sort-last tile flags (FrameView::touched) live behind the keys, in the allocation the peers open
     if (r->vis.alloc(npx + (rdr_touched_words(width, height) + 1) / 2) || r->color.alloc(npx * 4) || r->counters.alloc(2) || r->shadow.alloc((npx + 15) / 16 * 16) ||
-        r->pixel_list.alloc(npx)) return 1;
+        r->pixel_list.alloc(npx) || r->pixel_key.alloc(npx)) return 1;
     // depth pyramid: W/2 x H/2 and its mips, a little over a third of a pixel count
     if (r->pyramid.alloc(npx / 2 + width + height + 64)) return 1; // sum over levels <= W*H/3 + W + H + levels
     {
@@ -636,12 +640,30 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
     if (r->draws.upload(s.mesh_draws, s.draw_count)) return 1;
     if (r->materials.upload(s.materials, s.material_count)) return 1;
     if (r->transforms.upload(s.global_transforms, (size_t)s.transform_count * 16)) return 1;
-    if (r->draw_lod.alloc(s.draw_count) || r->draw_visible.alloc(std::max<size_t>(s.draw_count, 1)) ||
+    if (r->draw_lod.alloc(s.draw_count) || r->draw_frame.alloc(std::max<size_t>(s.draw_count, 1)) || r->draw_visible.alloc(std::max<size_t>(s.draw_count, 1)) ||
         r->meshlet_bits.alloc(((size_t)s.meshlet_visibility_count + 31) / 32 + 1)) return 1;
     // nothing was visible "last frame": the first frame's early phase draws nothing, its late phase everything
     RDR_HIP(hipMemset(r->draw_visible.ptr, 0, r->draw_visible.count));
     RDR_HIP(hipMemset(r->meshlet_bits.ptr, 0, r->meshlet_bits.count * sizeof(uint32_t)));
     RDR_HIP(hipMemset(r->draw_lod.ptr, 0xFF, std::max<size_t>(s.draw_count, 1)));
+    RDR_HIP(hipMemset(r->draw_frame.ptr, 0, std::max<size_t>(s.draw_count, 1) * sizeof(DrawFrame)));
+    {
+        // (meshlet, triangle) -> the triangle's three vertices relative to its mesh: what the shading passes would
+        // otherwise find through the meshlet record, three index bytes and three meshlet_vertices entries
+        std::vector<TriVertices> table((size_t)std::max<uint32_t>(s.meshlet_count, 1) * kTriTableStride, TriVertices{{0u, 0u, 0u}});
+        for (uint32_t me = 0; me < s.mesh_count; ++me) // the meshlets the meshes use (the ones validate_scene has checked)
+            for (uint32_t l = 0; l < s.meshes[me].lod_count; ++l) {
+                const rdr_mesh_lod& L = s.meshes[me].lods[l];
+                for (uint32_t mi = L.meshlet_offset; mi < L.meshlet_offset + L.meshlet_count; ++mi) {
+                    const rdr_meshlet& ml = s.meshlets[mi];
+                    const uint32_t nt = std::min<uint32_t>(ml.triangle_count, kTriTableStride);
+                    for (uint32_t t = 0; t < nt; ++t)
+                        for (int k = 0; k < 3; ++k)
+                            table[(size_t)mi * kTriTableStride + t].v[k] = s.meshlet_vertices[ml.vertex_offset + s.meshlet_triangles[ml.triangle_offset + 3 * t + k]];
+                }
+            }
+        if (r->tri_table.upload(table.data(), table.size())) return 1;
+    }
 
     // meshlet instance -> draw, and work-list capacities
     uint64_t cmd_cap = 0, vis_cap = 0, tri_total = 0, masked_total = 0;
@@ -747,6 +769,8 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
     sv.transforms = r->transforms.ptr;
     sv.instance_draw = r->instance_draw.ptr;
     sv.draw_lod = r->draw_lod.ptr;
+    sv.draw_frame = r->draw_frame.ptr;
+    sv.tri_table = r->tri_table.ptr;
     sv.images = r->images.ptr;
     sv.texels = r->texels.ptr;
     sv.srgb_lut = r->srgb_lut.ptr;

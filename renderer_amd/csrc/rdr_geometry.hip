@@ -136,7 +136,15 @@ __global__ __launch_bounds__(256) void k_draw_cull(SceneView sv, FrameView fv) {
             }
             emitted = true;
         }
-        if (PHASE != kPhaseEarly) sv.draw_lod[di] = (uint8_t)lod; // the late phase sees every draw the early one saw
+        if (PHASE != kPhaseEarly) { // the late phase sees every draw the early one saw
+            sv.draw_lod[di] = (uint8_t)lod;
+            DrawFrame df;
+            df.meshlet_base = lod_meshlet_offset - d.meshlet_visibility_offset;
+            df.model_index = d.model_index;
+            df.material_lod = (uint32_t)d.material_index | (lod << 16);
+            df.mesh_vertex_offset = mesh->vertex_offset;
+            sv.draw_frame[di] = df;
+        }
     }
 
     // wave-level compaction: one atomic per wave reserves the commands of 64 draws

@@ -264,6 +264,24 @@ struct GpuInstance {
 };
 
 // Everything the kernels read, passed by value.
+// What the shading passes need of a draw, written per frame by the draw cull next to draw_lod: with it a
+// pixel's key leads to its triangle's vertices in three dependent loads (instance_draw -> draw_frame ->
+// tri_table) instead of six (instance_draw -> draws -> meshes / draw_lod -> meshlets -> triangle bytes ->
+// meshlet_vertices); those chains of round trips, not bandwidth, are what the two passes spend their time on.
+struct DrawFrame {
+    uint32_t meshlet_base;       // chosen LOD's meshlet_offset - the draw's meshlet_visibility_offset (wraps): + instance = meshlet
+    uint32_t model_index;
+    uint32_t material_lod;       // material_index | lod << 16
+    uint32_t mesh_vertex_offset;
+};
+static_assert(sizeof(DrawFrame) == 16, "DrawFrame layout");
+// The three vertices of triangle t of meshlet m, relative to the mesh's first vertex, at index m * 128 + t
+// (built once per scene from meshlet_triangles and meshlet_vertices).
+struct TriVertices {
+    uint32_t v[3];
+};
+constexpr uint32_t kTriTableStride = 128;
+
 struct SceneView {
     const rdr_vertex* vertices;
     const float* pos_x;
@@ -280,6 +298,8 @@ struct SceneView {
     const uint32_t* instance_draw; // meshlet instance -> draw id
     const float4* instance_ball;   // per draw: see GpuInstance::outer_radius
     uint8_t* draw_lod;             // per frame: LOD each draw selected, 0xFF = not drawn
+    DrawFrame* draw_frame;         // per frame, per draw (same writer)
+    const TriVertices* tri_table;  // per (meshlet, triangle)
     const GpuImage* images;
     const uint8_t* texels;
     const float* srgb_lut;
@@ -321,6 +341,7 @@ struct FrameView {
     uint32_t command_capacity, visible_capacity, deferred_capacity;
     uint32_t collect_stats;
     uint32_t* pixel_list; // indices of the covered pixels in the shaded rows (k_classify)
+    uint32_t* pixel_key;  // per pixel_list entry: the low word of the pixel's key, (instance << 7) | triangle
     uint8_t* shadow;      // one byte per pixel_list entry: 1 = the sun ray is blocked (padded to a multiple of 16 bytes)
     SetupTri* setup;
     SetupMask* setup_mask;

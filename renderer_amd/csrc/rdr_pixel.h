@@ -82,15 +82,28 @@ RDR_DEV void decode_key(const SceneView& sv, unsigned long long key, uint32_t& d
     meshlet = L.meshlet_offset + (instance - d.meshlet_visibility_offset);
 }
 
+// A covered-pixel list entry resolved to what the shading passes work on.
 struct ListedPixel {
-    uint32_t pi, draw_id, meshlet, tri;
+    uint32_t pi, draw_id, tri, lod;
+    uint32_t i1, i2, i3; // the triangle's vertices (absolute)
+    uint32_t model_index, material_index;
     float uvx, uvy;
 };
 
 RDR_DEV ListedPixel listed_pixel(const SceneView& sv, const FrameView& fv, uint32_t entry) {
     ListedPixel p;
     p.pi = fv.pixel_list[entry];
-    decode_key(sv, fv.vis[p.pi], p.draw_id, p.meshlet, p.tri);
+    const uint32_t id = fv.pixel_key[entry], instance = id >> 7;
+    p.tri = id & 127u;
+    p.draw_id = sv.instance_draw[instance];
+    const DrawFrame df = sv.draw_frame[p.draw_id];
+    const TriVertices tv = sv.tri_table[(size_t)(df.meshlet_base + instance) * kTriTableStride + p.tri];
+    p.i1 = df.mesh_vertex_offset + tv.v[0];
+    p.i2 = df.mesh_vertex_offset + tv.v[1];
+    p.i3 = df.mesh_vertex_offset + tv.v[2];
+    p.model_index = df.model_index;
+    p.material_index = df.material_lod & 0xFFFFu;
+    p.lod = df.material_lod >> 16;
     const uint32_t iy = p.pi / fv.width, ix = p.pi - iy * fv.width;
     p.uvx = ((float)ix + 0.5f) / (float)fv.width;
     p.uvy = 1.0f - ((float)iy + 0.5f) / (float)fv.height;

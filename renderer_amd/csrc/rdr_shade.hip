@@ -29,10 +29,10 @@ RDR_DEV InterpUv uv_transform(InterpUv in, float sx, float sy, float ox, float o
     return r;
 }
 
-RDR_DEV vec4 sample_or_default(const SceneView& sv, uint32_t tex, InterpUv uv, vec4 def) {
+RDR_DEV vec4 sample_or_default(const SceneView& sv, const float* lut, uint32_t tex, InterpUv uv, vec4 def) {
     if (tex == RDR_NO_TEXTURE) return def;
     if (tex >= sv.image_count || sv.images[tex].mip_count == 0u) return mk4(0.0f, 0.0f, 0.0f, 0.0f);
-    return image_sample_grad(sv.images[tex], sv.texels, sv.srgb_lut, uv.u, uv.v, uv.dudx, uv.dvdx, uv.dudy, uv.dvdy);
+    return image_sample_grad(sv.images[tex], sv.texels, lut, uv.u, uv.v, uv.dudx, uv.dvdx, uv.dudy, uv.dvdy);
 }
 
 // ---- BRDF terms -------------------------------------------------------------------
@@ -156,25 +156,21 @@ RDR_DEV uint32_t srgb_encode(float c) {
     return (uint32_t)floorf(e * 255.0f + 0.5f);
 }
 
-RDR_DEV vec3 shade_pixel(const SceneView& sv, const rdr_ubo& u, uint32_t draw_id, uint32_t meshlet_index, uint32_t tri,
-                         float uvx, float uvy, bool shadow_hit) {
-    const rdr_mesh_draw d = sv.draws[draw_id];
-    const uint32_t mesh_vertex_offset = sv.meshes[d.mesh_index].vertex_offset;
+// `srgb`: the sRGB decode table (SceneView::srgb_lut or a copy of it)
+RDR_DEV vec3 shade_pixel(const SceneView& sv, const float* srgb, const rdr_ubo& u, const ListedPixel& px, bool shadow_hit) {
+    const float uvx = px.uvx, uvy = px.uvy;
     float model[16];
-    load_m4(sv.transforms + (size_t)d.model_index * 16, model);
+    load_m4(sv.transforms + (size_t)px.model_index * 16, model);
     rdr_material mat;
-    if (d.material_index < sv.material_count) {
-        mat = sv.materials[d.material_index];
+    if (px.material_index < sv.material_count) {
+        mat = sv.materials[px.material_index];
     } else { // robust buffer access: zeros
         uint32_t* z = reinterpret_cast<uint32_t*>(&mat);
         for (uint32_t i = 0; i < sizeof(mat) / 4; ++i) z[i] = 0u;
     }
-    const rdr_meshlet* ml = &sv.meshlets[meshlet_index];
-    const uint8_t* tp = sv.meshlet_triangles + ml->triangle_offset + tri * 3;
-    const uint32_t* mv = sv.meshlet_vertices + ml->vertex_offset;
-    const rdr_vertex* v1 = &sv.vertices[mesh_vertex_offset + mv[tp[0]]];
-    const rdr_vertex* v2 = &sv.vertices[mesh_vertex_offset + mv[tp[1]]];
-    const rdr_vertex* v3 = &sv.vertices[mesh_vertex_offset + mv[tp[2]]];
+    const rdr_vertex* v1 = &sv.vertices[px.i1];
+    const rdr_vertex* v2 = &sv.vertices[px.i2];
+    const rdr_vertex* v3 = &sv.vertices[px.i3];
 
     const vec4 w1 = mul_m4(model, mk4(v1->p[0], v1->p[1], v1->p[2], 1.0f));
     const vec4 w2 = mul_m4(model, mk4(v2->p[0], v2->p[1], v2->p[2], 1.0f));
@@ -191,27 +187,27 @@ RDR_DEV vec3 shade_pixel(const SceneView& sv, const rdr_ubo& u, uint32_t draw_id
                           dot3(us, bary.ddy), dot3(vs, bary.ddy)};
 
     const vec4 one = mk4(1.0f, 1.0f, 1.0f, 1.0f), nmap_def = mk4(0.5f, 0.5f, 1.0f, 0.0f);
-    vec4 albedo = sample_or_default(sv, mat.albedo_texture,
+    vec4 albedo = sample_or_default(sv, srgb, mat.albedo_texture,
                                     uv_transform(uv0, mat.albedo_texture_transform[0], mat.albedo_texture_transform[1],
                                                  mat.albedo_texture_transform[2], mat.albedo_texture_transform[3]), one);
     albedo.x *= mat.base_color_factor[0]; albedo.y *= mat.base_color_factor[1];
     albedo.z *= mat.base_color_factor[2]; albedo.w *= mat.base_color_factor[3];
-    const vec4 nm4 = sample_or_default(sv, mat.normal_texture,
+    const vec4 nm4 = sample_or_default(sv, srgb, mat.normal_texture,
                                        uv_transform(uv0, mat.normal_texture_transform[0], mat.normal_texture_transform[1],
                                                     mat.normal_texture_transform[2], mat.normal_texture_transform[3]), nmap_def);
     const vec3 nmap = mk3(nm4.x * 2.0f - 1.0f, nm4.y * 2.0f - 1.0f, nm4.z * 2.0f - 1.0f);
-    const vec4 mr = sample_or_default(sv, mat.metallic_roughness_texture,
+    const vec4 mr = sample_or_default(sv, srgb, mat.metallic_roughness_texture,
                                       uv_transform(uv0, mat.metallic_roughness_texture_transform[0], mat.metallic_roughness_texture_transform[1],
                                                    mat.metallic_roughness_texture_transform[2], mat.metallic_roughness_texture_transform[3]), one);
-    const vec4 occ = sample_or_default(sv, mat.occlusion_texture,
+    const vec4 occ = sample_or_default(sv, srgb, mat.occlusion_texture,
                                        uv_transform(uv0, mat.occlusion_texture_transform[0], mat.occlusion_texture_transform[1],
                                                     mat.occlusion_texture_transform[2], mat.occlusion_texture_transform[3]), one);
     const InterpUv uv_id = uv_transform(uv0, 1.0f, 1.0f, 0.0f, 0.0f);
-    const vec4 em4 = sample_or_default(sv, mat.emissive_texture, uv_id, one);
+    const vec4 em4 = sample_or_default(sv, srgb, mat.emissive_texture, uv_id, one);
     const vec3 emissive = mk3(mat.emissive_factor_alpha_cutoff[0] * em4.x, mat.emissive_factor_alpha_cutoff[1] * em4.y,
                               mat.emissive_factor_alpha_cutoff[2] * em4.z);
-    const vec4 sc4 = sample_or_default(sv, mat.specular_color_texture, uv_id, one);
-    const vec4 sp4 = sample_or_default(sv, mat.specular_texture, uv_id, one);
+    const vec4 sc4 = sample_or_default(sv, srgb, mat.specular_color_texture, uv_id, one);
+    const vec4 sp4 = sample_or_default(sv, srgb, mat.specular_texture, uv_id, one);
     const vec3 spec_color_factor = mk3(mat.specular_factor[0] * sc4.x, mat.specular_factor[1] * sc4.y, mat.specular_factor[2] * sc4.z);
     const float spec_factor_w = mat.specular_factor[3] * sp4.x;
 
@@ -273,7 +269,7 @@ RDR_DEV vec3 shade_pixel(const SceneView& sv, const rdr_ubo& u, uint32_t draw_id
     color = clamp01(((ibl_s + ibl_d) + color) + emissive) * occ.x;
 
     if (mat.material_type & RDR_MAT_CLEARCOAT) {
-        const vec4 cn4 = sample_or_default(sv, mat.clearcoat_texture, uv_id, nmap_def);
+        const vec4 cn4 = sample_or_default(sv, srgb, mat.clearcoat_texture, uv_id, nmap_def);
         const vec3 cm = mk3(cn4.x * 2.0f - 1.0f, cn4.y * 2.0f - 1.0f, cn4.z * 2.0f - 1.0f);
         const vec3 cnrm = normalize3((ntangent * cm.x + bitangent * cm.y) + nnormal * cm.z);
         const float cndv = clampf(fabsf(dot3(cnrm, v)), 0.001f, 1.0f);
@@ -298,13 +294,20 @@ RDR_DEV vec3 shade_pixel(const SceneView& sv, const rdr_ubo& u, uint32_t draw_id
 // case (every pixel covered); workgroups beyond the list's end exit on their first load, which costs nothing
 // measurable (a grid cut to the list's length ran in the same time).
 __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv) {
+    // the sRGB decode table in LDS: a trilinear tap of an sRGB texture looks up 24 values, each a dependent load
+    // behind its texel if the table stays in memory
+    __shared__ float lut[256];
     const uint32_t entry = blockIdx.x * 256u + threadIdx.x;
     if (entry == 0u) // last kernel of the shading half that every frame runs: the frame's status for the host
         __hip_atomic_store(&fv.host_status[1], (fv.frame_seq << 8) | (fv.counters->deep_overflow ? RDR_FRAME_SHADOW_STACK : 0u),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (entry >= fv.counters->pixel_count) return;
+    const uint32_t count = fv.counters->pixel_count;
+    if (blockIdx.x * 256u >= count) return; // the whole workgroup
+    lut[threadIdx.x] = sv.srgb_lut[threadIdx.x];
+    __syncthreads();
+    if (entry >= count) return;
     const ListedPixel p = listed_pixel(sv, fv, entry);
-    const vec3 c = shade_pixel(sv, fv.ubo, p.draw_id, p.meshlet, p.tri, p.uvx, p.uvy, fv.shadow[entry] != 0);
+    const vec3 c = shade_pixel(sv, lut, fv.ubo, p, fv.shadow[entry] != 0);
     reinterpret_cast<uint32_t*>(fv.color)[p.pi] =
         srgb_encode(c.x) | (srgb_encode(c.y) << 8) | (srgb_encode(c.z) << 16) | (255u << 24);
 }

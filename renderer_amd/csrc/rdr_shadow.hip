@@ -310,21 +310,14 @@ RDR_DEV bool shadow_any_hit(const SceneView& sv, uint32_t own_instance, bool ski
 
 // World-space position of the surface point seen through a pixel (the shadow ray's origin).
 // `face_normal`: (w2 - w1) x (w3 - w1) of the pixel's triangle in world space, not normalised.
-RDR_DEV vec3 pixel_world_position(const SceneView& sv, const rdr_ubo& u, uint32_t draw_id, uint32_t meshlet_index,
-                                  uint32_t tri, float uvx, float uvy, vec3& face_normal) {
-    const rdr_mesh_draw d = sv.draws[draw_id];
-    const uint32_t mesh_vertex_offset = sv.meshes[d.mesh_index].vertex_offset;
+RDR_DEV vec3 pixel_world_position(const SceneView& sv, const rdr_ubo& u, const ListedPixel& p, vec3& face_normal) {
     float model[16];
-    load_m4(sv.transforms + (size_t)d.model_index * 16, model);
-    const rdr_meshlet* ml = &sv.meshlets[meshlet_index];
-    const uint8_t* tp = sv.meshlet_triangles + ml->triangle_offset + tri * 3;
-    const uint32_t* mv = sv.meshlet_vertices + ml->vertex_offset;
-    const uint32_t i1 = mesh_vertex_offset + mv[tp[0]], i2 = mesh_vertex_offset + mv[tp[1]], i3 = mesh_vertex_offset + mv[tp[2]];
-    const vec4 w1 = mul_m4(model, mk4(sv.pos_x[i1], sv.pos_y[i1], sv.pos_z[i1], 1.0f));
-    const vec4 w2 = mul_m4(model, mk4(sv.pos_x[i2], sv.pos_y[i2], sv.pos_z[i2], 1.0f));
-    const vec4 w3 = mul_m4(model, mk4(sv.pos_x[i3], sv.pos_y[i3], sv.pos_z[i3], 1.0f));
+    load_m4(sv.transforms + (size_t)p.model_index * 16, model);
+    const vec4 w1 = mul_m4(model, mk4(sv.pos_x[p.i1], sv.pos_y[p.i1], sv.pos_z[p.i1], 1.0f));
+    const vec4 w2 = mul_m4(model, mk4(sv.pos_x[p.i2], sv.pos_y[p.i2], sv.pos_z[p.i2], 1.0f));
+    const vec4 w3 = mul_m4(model, mk4(sv.pos_x[p.i3], sv.pos_y[p.i3], sv.pos_z[p.i3], 1.0f));
     const vec4 c1 = mul_m4(u.view_proj, w1), c2 = mul_m4(u.view_proj, w2), c3 = mul_m4(u.view_proj, w3);
-    const BaryDeriv bary = calc_full_bary(c1, c2, c3, uvx * 2.0f - 1.0f, uvy * 2.0f - 1.0f, u.screen_width, u.screen_height);
+    const BaryDeriv bary = calc_full_bary(c1, c2, c3, p.uvx * 2.0f - 1.0f, p.uvy * 2.0f - 1.0f, u.screen_width, u.screen_height);
     face_normal = cross3(mk3(w2.x - w1.x, w2.y - w1.y, w2.z - w1.z), mk3(w3.x - w1.x, w3.y - w1.y, w3.z - w1.z));
     return interp3(bary, mk3(w1.x, w1.y, w1.z), mk3(w2.x, w2.y, w2.z), mk3(w3.x, w3.y, w3.z));
 }
@@ -333,9 +326,9 @@ RDR_DEV vec3 pixel_world_position(const SceneView& sv, const rdr_ubo& u, uint32_
 // convex surface (GpuInstance::convex_cos != 0), the pixel shows a triangle of the very mesh the ray
 // structure holds (level of detail 0) and the ray leaves that triangle's plane outwards by more than the
 // instance's margin: the whole mesh lies behind the plane, so no triangle of it can be hit beyond tmin.
-RDR_DEV bool leaves_convex_mesh(const SceneView& sv, uint32_t draw_id, vec3 face_normal, vec3 L) {
+RDR_DEV bool leaves_convex_mesh(const SceneView& sv, uint32_t draw_id, uint32_t lod, vec3 face_normal, vec3 L) {
     const float c = sv.instances[draw_id].convex_cos;
-    if (c == 0.0f || sv.draw_lod[draw_id] != 0) return false;
+    if (c == 0.0f || lod != 0u) return false;
     const float out = c > 0.0f ? dot3(face_normal, L) : -dot3(face_normal, L);
     return out > fabsf(c) * len3(face_normal);
 }
@@ -358,6 +351,7 @@ __global__ __launch_bounds__(1024) void k_classify(FrameView fv) {
     const uint32_t x0 = blockIdx.x * kClassifyRegion + (quad & 1u) * 64 + (wave & 1u) * 8 + (lane & 7u);
     const uint32_t y0 = fv.row_lo + blockIdx.y * kClassifyRegion + (quad >> 1) * 64 + (wave >> 1) * 8 + (lane >> 3);
     uint32_t covered_bits = 0;
+    uint32_t ids[16]; // low words of the covered pixels' keys, for the list
     uint32_t* color = reinterpret_cast<uint32_t*>(fv.color);
 #pragma unroll
     for (uint32_t b = 0; b < 16; ++b) {
@@ -365,7 +359,9 @@ __global__ __launch_bounds__(1024) void k_classify(FrameView fv) {
         bool covered = false;
         if (ix < fv.width && iy < fv.row_hi) {
             const uint32_t pi = iy * fv.width + ix;
-            covered = fv.vis[pi] != RDR_VIS_CLEAR;
+            const unsigned long long key = fv.vis[pi];
+            covered = key != RDR_VIS_CLEAR;
+            ids[b] = (uint32_t)key;
             if (!covered) color[pi] = 0u; // the shading pass clears its target to (0,0,0,0)
         }
         const unsigned long long m = __ballot(covered);
@@ -399,7 +395,9 @@ __global__ __launch_bounds__(1024) void k_classify(FrameView fv) {
         const unsigned long long m = __ballot(covered);
         if (covered) {
             const uint32_t ix = x0 + (b & 3u) * 16, iy = y0 + (b >> 2) * 16;
-            fv.pixel_list[base + wave_count[quad * 64 + b * 4 + wave] + ballot_rank(m)] = iy * fv.width + ix;
+            const uint32_t at = base + wave_count[quad * 64 + b * 4 + wave] + ballot_rank(m);
+            fv.pixel_list[at] = iy * fv.width + ix;
+            fv.pixel_key[at] = ids[b];
         }
     }
 }
@@ -419,10 +417,10 @@ RDR_DEV ShadowRay shadow_ray_of(const SceneView& sv, const FrameView& fv, uint32
     const ListedPixel p = listed_pixel(sv, fv, entry);
     vec3 face_normal;
     ShadowRay r;
-    r.o = pixel_world_position(sv, fv.ubo, p.draw_id, p.meshlet, p.tri, p.uvx, p.uvy, face_normal);
+    r.o = pixel_world_position(sv, fv.ubo, p, face_normal);
     r.d = normalize3(mk3(fv.ubo.sun_direction[0], fv.ubo.sun_direction[1], fv.ubo.sun_direction[2]));
     r.draw_id = p.draw_id;
-    r.skip_own = (fv.convex_skip & 1u) && leaves_convex_mesh(sv, p.draw_id, face_normal, r.d);
+    r.skip_own = (fv.convex_skip & 1u) && leaves_convex_mesh(sv, p.draw_id, p.lod, face_normal, r.d);
     return r;
 }
 constexpr float kShadowTmin = 1e-2f, kShadowTmax = 1000.0f;
