@@ -638,7 +638,14 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
     if (r->meshlets.upload(s.meshlets, s.meshlet_count)) return 1;
     if (r->meshes.upload(s.meshes, s.mesh_count)) return 1;
     if (r->draws.upload(s.mesh_draws, s.draw_count)) return 1;
-    if (r->materials.upload(s.materials, s.material_count)) return 1;
+    {
+        // one all-zero material behind the scene's: an index past the end reads zeros (robust buffer access) through
+        // the same pointer arithmetic as a valid one
+        std::vector<rdr_material> mats((size_t)s.material_count + 1);
+        std::memset(static_cast<void*>(mats.data()), 0, mats.size() * sizeof(rdr_material));
+        if (s.material_count) std::memcpy(static_cast<void*>(mats.data()), s.materials, (size_t)s.material_count * sizeof(rdr_material));
+        if (r->materials.upload(mats.data(), mats.size())) return 1;
+    }
     if (r->transforms.upload(s.global_transforms, (size_t)s.transform_count * 16)) return 1;
     if (r->draw_lod.alloc(s.draw_count) || r->draw_frame.alloc(std::max<size_t>(s.draw_count, 1)) || r->draw_visible.alloc(std::max<size_t>(s.draw_count, 1)) ||
         r->meshlet_bits.alloc(((size_t)s.meshlet_visibility_count + 31) / 32 + 1)) return 1;

@@ -161,13 +161,9 @@ RDR_DEV vec3 shade_pixel(const SceneView& sv, const float* srgb, const rdr_ubo& 
     const float uvx = px.uvx, uvy = px.uvy;
     float model[16];
     load_m4(sv.transforms + (size_t)px.model_index * 16, model);
-    rdr_material mat;
-    if (px.material_index < sv.material_count) {
-        mat = sv.materials[px.material_index];
-    } else { // robust buffer access: zeros
-        uint32_t* z = reinterpret_cast<uint32_t*>(&mat);
-        for (uint32_t i = 0; i < sizeof(mat) / 4; ++i) z[i] = 0u;
-    }
+    // fields are read where they are used (the copy of all 272 bytes held some forty registers through the texture taps);
+    // an index past the end lands on the zero material the upload appends
+    const rdr_material& mat = sv.materials[px.material_index < sv.material_count ? px.material_index : sv.material_count];
     const rdr_vertex* v1 = &sv.vertices[px.i1];
     const rdr_vertex* v2 = &sv.vertices[px.i2];
     const rdr_vertex* v3 = &sv.vertices[px.i3];
@@ -293,7 +289,7 @@ RDR_DEV vec3 shade_pixel(const SceneView& sv, const float* srgb, const rdr_ubo& 
 // Pass 2: material evaluation, lighting, sRGB store of every covered pixel.  The grid is sized for the worst
 // case (every pixel covered); workgroups beyond the list's end exit on their first load, which costs nothing
 // measurable (a grid cut to the list's length ran in the same time).
-__global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_shade(SceneView sv, FrameView fv) {
     // the sRGB decode table in LDS: a trilinear tap of an sRGB texture looks up 24 values, each a dependent load
     // behind its texel if the table stays in memory
     __shared__ float lut[256];
