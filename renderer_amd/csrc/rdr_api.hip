@@ -749,6 +749,7 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
         if (pack_cubemap(tp, s.env ? &s.env->charlie : nullptr, &r->sv.charlie)) return 1;
         if (pack_cubemap(tp, s.env ? &s.env->skybox : nullptr, &r->sv.skybox)) return 1;
         if (r->images.upload(imgs.data(), imgs.size())) return 1;
+        tp.blob.resize(tp.blob.size() + 16); // slack: a bilinear tap at an image's last texel reads eight bytes from it
         if (r->texels.upload(tp.blob.data(), tp.blob.size())) return 1;
         if (decode_block_images(tp, r->texels.ptr)) return 1;
     }

@@ -137,20 +137,52 @@ RDR_DEV int wrap_repeat(int i, int n) {
     return m < 0 ? m + n : m;
 }
 
+RDR_DEV vec4 decode_rgba8(uint32_t t, uint32_t format, const float* srgb_lut) {
+    const uint32_t r = t & 255u, g = (t >> 8) & 255u, b = (t >> 16) & 255u, a = t >> 24;
+    if (format == RDR_FORMAT_RGBA8_SRGB)
+        return mk4(srgb_lut[r], srgb_lut[g], srgb_lut[b], unorm8(a));
+    return mk4(unorm8(r), unorm8(g), unorm8(b), unorm8(a));
+}
+
+// Two horizontally adjacent 4-byte texels with one 8-byte load (the address is only 4-byte aligned, which the
+// memory path accepts).  At the last column the second word belongs to the next row, or to the slack behind the
+// texel blob: the caller replaces it.
+struct TexelPair {
+    uint32_t a, b;
+};
+RDR_DEV TexelPair load_texel_pair(const uint8_t* p) {
+    typedef uint32_t __attribute__((ext_vector_type(2), aligned(4))) u32x2_a4;
+    const u32x2_a4 v = *reinterpret_cast<const u32x2_a4*>(p);
+    return TexelPair{v.x, v.y};
+}
+
 RDR_DEV vec4 image_bilinear(const GpuImage& im, const uint8_t* texels, const float* lut, uint32_t level,
                             float u, float v) {
     const int w = (int)mip_dim(im.width, level), h = (int)mip_dim(im.height, level);
-    const uint32_t tb = im.format == RDR_FORMAT_RGBA32F ? 16u : 4u;
     const uint8_t* base = texels + im.offset + im.level_offset[level];
     const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
     const float fx = floorf(x), fy = floorf(y);
     const float ax = x - fx, ay = y - fy;
     const int x0 = wrap_repeat((int)fx, w), x1 = wrap_repeat((int)fx + 1, w);
     const int y0 = wrap_repeat((int)fy, h), y1 = wrap_repeat((int)fy + 1, h);
-    const vec4 t00 = decode_texel(base + ((size_t)y0 * w + x0) * tb, im.format, lut);
-    const vec4 t10 = decode_texel(base + ((size_t)y0 * w + x1) * tb, im.format, lut);
-    const vec4 t01 = decode_texel(base + ((size_t)y1 * w + x0) * tb, im.format, lut);
-    const vec4 t11 = decode_texel(base + ((size_t)y1 * w + x1) * tb, im.format, lut);
+    vec4 t00, t10, t01, t11;
+    if (im.format == RDR_FORMAT_RGBA32F) {
+        t00 = decode_texel(base + ((size_t)y0 * w + x0) * 16u, im.format, lut);
+        t10 = decode_texel(base + ((size_t)y0 * w + x1) * 16u, im.format, lut);
+        t01 = decode_texel(base + ((size_t)y1 * w + x0) * 16u, im.format, lut);
+        t11 = decode_texel(base + ((size_t)y1 * w + x1) * 16u, im.format, lut);
+    } else {
+        // a footprint's two texels of a row are neighbours in memory unless it wraps around the last column:
+        // four loads per tap become two, and the address unit is what the textured passes keep busiest
+        TexelPair r0 = load_texel_pair(base + ((size_t)y0 * w + x0) * 4u);
+        TexelPair r1 = load_texel_pair(base + ((size_t)y1 * w + x0) * 4u);
+        if (x1 != x0 + 1) {
+            r0.b = *reinterpret_cast<const uint32_t*>(base + ((size_t)y0 * w + x1) * 4u);
+            r1.b = *reinterpret_cast<const uint32_t*>(base + ((size_t)y1 * w + x1) * 4u);
+        }
+        t00 = decode_rgba8(r0.a, im.format, lut); t10 = decode_rgba8(r0.b, im.format, lut);
+        t01 = decode_rgba8(r1.a, im.format, lut); t11 = decode_rgba8(r1.b, im.format, lut);
+    }
     return lerp4(lerp4(t00, t10, ax), lerp4(t01, t11, ax), ay);
 }
 
