@@ -33,7 +33,8 @@ def algorithmic_bytes(st, width, height, draws):
     """Bytes each kernel must move per frame, from the frame's own counters: struct sizes are
     the reference's GPU layouts (16 B draw, 64 B transform, 160 B mesh, 32 B meshlet, 32 B cull
     command, 16 B visible-meshlet record, 4 B vertex id + 12 B position, 3 B per triangle,
-    8 B per visibility key, 64 B vertex, 4 B RGBA8, 4 B covered-pixel list entry)."""
+    8 B per visibility key, 64 B vertex, 4 B RGBA8, 4 B covered-pixel list entry + 4 B key word,
+    4 B instance -> draw, 16 B per-frame draw record, 12 B triangle -> vertices entry)."""
     px = width * height
     cov = st["pixels_covered"]
     return {
@@ -45,10 +46,11 @@ def algorithmic_bytes(st, width, height, draws):
         "raster": st["meshlets_visible"] * (16 + 32) + st["vertices_transformed"] * (4 + 12)
                   + st["triangles_tested"] * 3 + st["fragments"] * 8,
         # classification: every key read once, a list entry per covered pixel, the clear colour elsewhere
-        "classify": px * 8 + cov * 4 + (px - cov) * 4,
-        # shadow pass: list entry + key + ids + 3 positions per covered pixel, 1 B result; BVH nodes are shared (L2)
-        "shadow": cov * (4 + 8 + 15 + 3 * 12 + 1),
-        "shade": cov * (4 + 8 + 1 + 15 + 3 * 64 + 4),
+        "classify": px * 8 + cov * 8 + (px - cov) * 4,
+        # shadow pass: list entry + key word + draw id + draw record + vertex ids + 3 positions per covered pixel,
+        # 1 B result; BVH nodes are shared (L2)
+        "shadow": cov * (4 + 4 + 4 + 16 + 12 + 3 * 12 + 1),
+        "shade": cov * (4 + 4 + 4 + 16 + 12 + 1 + 3 * 64 + 4),
     }
 
 
@@ -340,15 +342,18 @@ def main():
             "frame_minus_kernels_ms": round(ms - sum(kms.values()), 4),
             "launches_per_frame": {"all_opaque_no_occlusion": 10, "with_alpha_tested_draws": 12,
                                    "note": "dependent kernel launches of one frame on this path (draw cull, meshlet cull, raster, tile set-up, "
-                                           "mid + fill, tile raster, classify, shadow, deep shadow, shade; alpha-tested draws add two)"},
+                                           "mid + fill, tile raster, classify, shadow, shadow walk, shade; alpha-tested draws add two)"},
             "frame_counters": {k: st[k] for k in ("draws_visible", "meshlets_tested", "meshlets_visible",
                                                   "triangles_submitted", "triangles_tested", "triangles_rasterised",
                                                   "fragments", "pixels_covered", "vertices_transformed")},
             "roofline": {"kernel": "k_" + dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         # the contract's bound is HBM or MFMA; of the two this path can only meet HBM, but the dominant
-                         # kernel is a divergent tree walk limited by load latency and lane divergence, not by bandwidth
-                         "limited_by": "dependent-load latency and lane divergence (valu_issue: share of vector issue slots used, lanes active)",
+                         # the contract's bound is HBM or MFMA; of the two this path can only meet HBM, but none of the three
+                         # large kernels is limited by bandwidth (valu_issue: share of vector issue slots used, lanes active)
+                         "limited_by": {"raster": "vector issue and LDS round trips per meshlet (a third of the issue slots, two thirds of the lanes), "
+                                                  "then the rate of scattered 64-bit atomics",
+                                        "shade": "dependent-load latency at four waves per SIMD, then the address unit (about 60 % busy)",
+                                        "shadow": "dependent-load latency and lane divergence of the tree walk"}.get(dom, "memory"),
                          "algorithmic_bytes": ab_dom, "kernel_ms": t_dom,
                          "frame_algorithmic_bytes": sum(ab.values()),
                          "frame_frac": sum(ab.values()) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
