@@ -190,6 +190,29 @@ def test_shadow_deep_stack_path(oracle, monkeypatch):
     check_color(o, g)
 
 
+@pytest.mark.parametrize("lods,stack", [(1, None), (6, None), (1, "2")])
+def test_shadow_walk_kernel_equals_inline_walk(monkeypatch, lods, stack):
+    """The walks through a ray's own closed convex instance are left to k_shadow_walk by default; with
+    RDR_SHADOW_DEFER=0 they stay inside k_shadow.  Same shadow for every pixel either way, also where the pixel
+    shows a coarser level of detail than the ray structure holds and where the LDS stack overflows."""
+    sc = synth.make_field(300, 4, lods=lods, with_env=True, prepared=True)
+    conf = RendererConfig(lod_enabled=lods > 1, cull_enabled=False)
+    if stack:
+        monkeypatch.setenv("RDR_DEBUG_STACK_LIMIT", stack)
+    frames = {}
+    for defer in ("1", "0"):
+        monkeypatch.setenv("RDR_SHADOW_DEFER", defer)
+        g = Renderer(1280, 720, conf)
+        g.set_scene(sc)
+        g.render()
+        frames[defer] = (g.read_visbuffer_u64(), g.read_color())
+        assert g.frame_status() == 0
+        g.close()
+    assert np.array_equal(frames["1"][0], frames["0"][0])
+    assert np.array_equal(frames["1"][1], frames["0"][1])
+    assert covered(frames["1"][0]).sum() > 20000
+
+
 def test_known_answer_triangle():
     W = H = 64
     sc = fb_triangle_scene([[(8, 8, 5.0), (8, 40, 5.0), (40, 8, 5.0)]], W, H)
