@@ -106,6 +106,12 @@ struct rdr_renderer {
     DeviceBuffer<uint32_t> instance_draw;
     DeviceBuffer<uint8_t> draw_lod;
     DeviceBuffer<DrawFrame> draw_frame;
+    DeviceBuffer<float> instance_reach;
+    DeviceBuffer<uint8_t> sun_cand_count;
+    DeviceBuffer<float4> world_ball;
+    float sun_cand_dir[3] = {0, 0, 0}; // the sun direction the candidates were computed for
+    bool sun_cand_valid = false;       // ... with the current transforms
+    uint32_t sun_candidates = 1;       // measurement hook RDR_SUN_CANDIDATES=0: every shadow ray walks the top level
     DeviceBuffer<TriVertices> tri_table;
     DeviceBuffer<uint8_t> draw_visible;
     DeviceBuffer<uint32_t> meshlet_bits;
@@ -344,7 +350,20 @@ int upload_tlas(rdr_renderer* r) {
     const size_t blas_count = r->bvh.blas_pairs.size();
     RDR_CHECK(blas_count + r->bvh.tlas_pairs.size() <= r->bvh_dev.count, "internal: top-level BVH larger than reserved");
     RDR_HIP(hipMemcpy(r->bvh_dev.ptr + blas_count, r->bvh.tlas_pairs.data(), r->bvh.tlas_pairs.size() * sizeof(BvhWide), hipMemcpyHostToDevice));
-    if (r->tlas_items.upload(r->bvh.tlas_items.data(), r->bvh.tlas_items.size())) return 1;
+    {
+        // the top level's items, and behind them room for every instance's sun occluder candidates (k_sun_candidates)
+        const size_t n = r->bvh.tlas_items.size();
+        std::vector<uint32_t> items(n * (1 + kSunCandidates) + 1, 0u);
+        std::copy(r->bvh.tlas_items.begin(), r->bvh.tlas_items.end(), items.begin());
+        if (r->tlas_items.upload(items.data(), items.size())) return 1;
+        if (r->instance_reach.upload(r->bvh.instance_reach.data(), r->bvh.instance_reach.size())) return 1;
+        if (r->sun_cand_count.alloc(std::max<size_t>(n, 1))) return 1;
+        RDR_HIP(hipMemset(r->sun_cand_count.ptr, 0xFF, std::max<size_t>(n, 1)));
+        if (r->world_ball.alloc(std::max<size_t>(n, 1))) return 1;
+        RDR_HIP(hipMemset(r->world_ball.ptr, 0, std::max<size_t>(n, 1) * sizeof(float4)));
+        r->sun_cand_valid = false;
+        r->sv.sun_cand_base = (uint32_t)n;
+    }
     if (r->instances.upload(r->bvh.instances.data(), r->bvh.instances.size())) return 1;
     if (const char* e = std::getenv("RDR_INNER_BALL")) // measurement hook: 0 = no instance has an inner ball
         if (std::atoi(e) == 0) std::fill(r->bvh.instance_ball.begin(), r->bvh.instance_ball.end(), 0.0f);
@@ -352,6 +371,10 @@ int upload_tlas(rdr_renderer* r) {
     r->sv.bvh = r->bvh_dev.ptr;
     r->sv.tlas_base = (uint32_t)blas_count;
     r->sv.tlas_items = r->tlas_items.ptr;
+    r->sv.sun_cand_items = r->tlas_items.ptr + r->sv.sun_cand_base;
+    r->sv.sun_cand_count = r->sun_cand_count.ptr;
+    r->sv.world_ball = r->world_ball.ptr;
+    r->sv.instance_reach = r->instance_reach.ptr;
     r->sv.instances = r->instances.ptr;
     r->sv.instance_ball = r->instance_ball.ptr;
     return 0;
@@ -391,6 +414,7 @@ FrameView make_frame_view(rdr_renderer* r) {
     fv.lds_stack_limit = r->lds_stack_limit;
     fv.convex_skip = r->convex_skip;
     fv.shadow_defer = r->shadow_defer;
+    fv.sun_candidates = r->sun_candidates;
     fv.host_status = r->status_dev;
     fv.frame_seq = r->frame_seq & 0xFFFFFFu;
     fv.deferred_capacity = std::min(fv.deferred_capacity, r->debug_deferred_capacity);
@@ -566,6 +590,7 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
     }
     if (const char* e = std::getenv("RDR_TILE_FLAGS")) r->force_tile_flags = std::atoi(e) != 0;
     if (const char* e = std::getenv("RDR_CONVEX_SKIP")) r->convex_skip = std::atoi(e) != 0 ? 1u : 0u;
+    if (const char* e = std::getenv("RDR_SUN_CANDIDATES")) r->sun_candidates = std::atoi(e) != 0 ? 1u : 0u; // measurement hook
     if (const char* e = std::getenv("RDR_SHADOW_DEFER")) r->shadow_defer = std::atoi(e) != 0 ? 1u : 0u; // measurement hook
     if (const char* e = std::getenv("RDR_DEBUG_DEFERRED_CAPACITY")) // test hook: force the deferred list to overflow
         r->debug_deferred_capacity = (uint32_t)std::max(1, std::atoi(e));
@@ -862,6 +887,13 @@ int rdr_shade(rdr_renderer* r) {
     FrameView fv = make_frame_view(r);
     fv.list_heads_zero = r->shaded ? 0u : 1u; // first shading pass over this visibility buffer
     hipEvent_t* ev = r->timing_this_frame ? r->ring.data() + (size_t)r->cur_slot * rdr_renderer::kEvents : nullptr;
+    // which instances could block a sun ray that starts on a given instance: a function of the sun direction and the
+    // transforms, brought up to date here when either has changed since it was computed (a static scene pays once)
+    if (!r->sun_cand_valid || std::memcmp(r->sun_cand_dir, fv.ubo.sun_direction, sizeof(r->sun_cand_dir)) != 0) {
+        if (rdr_launch_sun_candidates(r->sv, fv, r->stream)) return 1;
+        std::memcpy(r->sun_cand_dir, fv.ubo.sun_direction, sizeof(r->sun_cand_dir));
+        r->sun_cand_valid = true;
+    }
     if (rdr_launch_shade(r->sv, fv, r->stream, ev)) return 1;
     r->shaded = true;
     if (ev) r->slot_shade[r->cur_slot] = true;

@@ -429,6 +429,7 @@ void rdr_build_blas(const rdr_scene_desc& s, HostBvh& out) {
     out.mesh_convex_sign.assign(s.mesh_count, 0);
     out.mesh_protrusion.assign(s.mesh_count, 0.0f);
     out.mesh_ball.assign(5 * (size_t)s.mesh_count, 0.0f);
+    out.mesh_reach.assign(s.mesh_count, 0.0f);
     std::vector<BvhNode> nodes;
     std::vector<Item> items;
     for (uint32_t mi = 0; mi < s.mesh_count; ++mi) {
@@ -477,6 +478,14 @@ void rdr_build_blas(const rdr_scene_desc& s, HostBvh& out) {
                 const double r_in = (cx.sign != 0 && cx.r_in > 0.0f) ? (double)cx.r_in * (1.0 - 3e-5) - 2.4e-7 * (cmax + std::sqrt(far2)) : 0.0;
                 out.mesh_ball[5 * (size_t)mi + 3] = r_in > 0.0 ? (float)r_in : 0.0f;
                 out.mesh_ball[5 * (size_t)mi + 4] = (float)(std::sqrt(far2) * 1.0001 + 1e-30);
+                // and the distance that holds every vertex of the mesh, whichever level of detail uses it: a pixel may show a
+                // coarser level than the ray structure holds, and its shadow ray starts there
+                double reach2 = far2;
+                for (uint32_t v = 0; v < mesh.vertex_count; ++v) {
+                    const float* p = s.vertices[mesh.vertex_offset + v].p;
+                    reach2 = std::max(reach2, (p[0] - c[0]) * (p[0] - c[0]) + (p[1] - c[1]) * (p[1] - c[1]) + (p[2] - c[2]) * (p[2] - c[2]));
+                }
+                out.mesh_reach[mi] = (float)(std::sqrt(reach2) * 1.0001 + 1e-30);
             }
         }
         out.mesh_root[mi] = (uint32_t)out.blas_pairs.size();
@@ -497,6 +506,7 @@ void rdr_build_tlas(const rdr_scene_desc& s, const float* transforms, HostBvh& i
     std::vector<Item> items(s.draw_count);
     io.instances.resize(s.draw_count);
     io.instance_ball.assign(4 * (size_t)s.draw_count, 0.0f);
+    io.instance_reach.assign(s.draw_count, 0.0f);
     for (uint32_t di = 0; di < s.draw_count; ++di) {
         const rdr_mesh_draw& d = s.mesh_draws[di];
         const float* m = transforms + (size_t)d.model_index * 16;
@@ -505,6 +515,7 @@ void rdr_build_tlas(const rdr_scene_desc& s, const float* transforms, HostBvh& i
         inst.blas_root = io.mesh_root[d.mesh_index];
         inst.tri_base = io.mesh_tri_base[d.mesh_index];
         inst.outer_radius = io.mesh_ball[5 * (size_t)d.mesh_index + 4];
+        io.instance_reach[di] = io.mesh_reach[d.mesh_index];
         inst.convex_cos = 0.0f;
         for (int k = 0; k < 4; ++k) io.instance_ball[4 * (size_t)di + k] = io.mesh_ball[5 * (size_t)d.mesh_index + k];
         const BvhNode& root = io.mesh_bounds[d.mesh_index];

@@ -243,6 +243,7 @@ constexpr uint32_t kLaneMaxPixels = 16, kMidMaxPixels = 1024; // defaults of the
 constexpr uint32_t kBvhNone = 0xFFFFFFFFu;
 constexpr uint32_t kBvhLeaf = 0x80000000u;
 constexpr uint32_t kBvhMaxLeaf = 127u;
+constexpr uint32_t kSunCandidates = 8; // occluder candidates kept per instance
 
 struct GpuInstance {
     float inv[12];      // rows of the inverse affine model matrix
@@ -297,6 +298,14 @@ struct SceneView {
     const float* transforms;
     const uint32_t* instance_draw; // meshlet instance -> draw id
     const float4* instance_ball;   // per draw: see GpuInstance::outer_radius
+    // Sun occluder candidates (k_sun_candidates, for one sun direction and one set of transforms): the instances
+    // that could block a sun ray starting anywhere on draw d are tlas_items[sun_cand_base + d * kSunCandidates ..]
+    // (sun_cand_count[d] of them); 255 = too many or unknown, walk the top level.
+    const float* instance_reach;   // per draw: object-space distance from instance_ball.xyz that holds every vertex of the mesh (all levels of detail)
+    uint8_t* sun_cand_count;
+    float4* world_ball;            // per draw (same kernel): world-space centre and radius of a ball around the LOD-0 mesh, w = 0: unknown
+    uint32_t* sun_cand_items;      // == tlas_items + sun_cand_base
+    uint32_t sun_cand_base;
     uint8_t* draw_lod;             // per frame: LOD each draw selected, 0xFF = not drawn
     DrawFrame* draw_frame;         // per frame, per draw (same writer)
     const TriVertices* tri_table;  // per (meshlet, triangle)
@@ -388,6 +397,7 @@ struct FrameView {
     uint32_t* host_status;
     uint32_t frame_seq;
     uint32_t convex_skip; // 1: shadow rays that leave a closed convex mesh skip that mesh (0 only as a measurement hook)
+    uint32_t sun_candidates; // 1: SceneView::sun_cand_* hold this frame's sun direction and transforms (0 only as a measurement hook)
     uint32_t shadow_defer; // 1: walks through a ray's own closed convex instance are left to k_shadow_walk (0 only as a measurement hook)
     // Per-workgroup statistics: every workgroup stores its partial counts in its own
     // slot with plain stores (no contended atomics); the host sums the slots on request.
@@ -407,6 +417,8 @@ struct HostBvh {
     std::vector<float> mesh_protrusion;     // per mesh: how far a vertex lies outside a face plane at most (object units)
     std::vector<float> mesh_ball;           // per mesh: centre, inner radius (0: none), outer radius (GpuInstance::outer_radius)
     std::vector<float> instance_ball;       // per instance: centre and inner radius, for the kernels
+    std::vector<float> mesh_reach;          // per mesh: distance from the ball's centre that holds every vertex of the mesh's vertex range
+    std::vector<float> instance_reach;      // per instance: its mesh's
     std::vector<BvhNode> tlas_nodes;
     std::vector<uint32_t> tlas_items;
     std::vector<GpuInstance> instances;
@@ -424,6 +436,7 @@ int rdr_geometry_residency(GeometryResidency* out, uint32_t fill_lds_bytes);
 // Dynamic LDS of k_mid_fill: one bin offset per 64x64 tile and the 256 partial sums of its prefix sum.
 inline uint32_t rdr_tile_fill_lds(uint32_t n_tiles) { return ((n_tiles + 1u) & ~1u) * 4u + 256u * 8u; }
 int rdr_launch_shadow(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev); // classify + shadow rays
+int rdr_launch_sun_candidates(const SceneView& sv, const FrameView& fv, hipStream_t stream); // SceneView::sun_cand_* for fv's sun direction
 int rdr_launch_shade(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev);  // the above, then k_shade
 // ---- peer-to-peer sort-last exchange (rdr_composite.hip) ----------------------------
 struct rdr_composite_state;

@@ -10,6 +10,7 @@
 namespace {
 
 // ---- shadow ray -------------------------------------------------------------------
+constexpr float kShadowTmin = 1e-2f, kShadowTmax = 1000.0f; // shading.frag.glsl:421-425
 // Conservative ray / box slab test on one child of a wide node.  `w` holds one axis of
 // the box as an fp16 pair (low half = box minimum, high half = box maximum).  Only "never
 // miss a box the ray touches" matters for the result, so the planes are evaluated as
@@ -234,15 +235,24 @@ RDR_DEV bool shadow_any_hit(const SceneView& sv, uint32_t own_instance, bool ski
         else if (mode == kTraceDefer && ball.w > 0.0f) { walk_own = false; deferred = true; }
     }
     if (mode == kTraceOwn && !walk_own) return false;
+    // The world level: the top-level tree from its root, or, where k_sun_candidates left a short list of the instances
+    // that can block a sun ray from this one, that list in the form of a top-level leaf (usually empty or one or two
+    // instances, against four to six dependent node steps through the tree).
+    uint32_t world = 0u; // node 0 of a tree holds the children of its root
+    const uint32_t n_cand = sv.sun_cand_count[own_instance];
+    if (n_cand <= kSunCandidates)
+        world = n_cand ? (kBvhLeaf | (n_cand << 24) | (sv.sun_cand_base + own_instance * kSunCandidates)) : kBvhNone;
+    if (mode == kTraceOwn) world = kBvhNone;
     if (!walk_own) {
+        if (world == kBvhNone) return false;
         ray = make_ray(o, d, tmax);
         t_hi = tmax;
-    } else {
-        st.push(0u); // node 0 of a tree holds the children of its root
+    } else if (world != kBvhNone) {
+        st.push(world);
     }
-    int floor = walk_own ? 1 : -1;
+    int floor = walk_own ? st.sp : -1;
     uint32_t node_base = walk_own ? sv.instances[own_instance].blas_root : sv.tlas_base, tri_base = sv.instances[own_instance].tri_base;
-    uint32_t cur = 0u;
+    uint32_t cur = walk_own ? 0u : world;
     bool hit = false;
     for (;;) {
         if (!(cur & kBvhLeaf)) {
@@ -280,7 +290,20 @@ RDR_DEV bool shadow_any_hit(const SceneView& sv, uint32_t own_instance, bool ski
                 // top-level leaf: take its first instance now, leave the others on the stack
                 const uint32_t instance = sv.tlas_items[first];
                 if (count > 1u) st.push(kBvhLeaf | ((count - 1u) << 24) | (first + 1u));
-                if (instance != own_instance) {
+                // the instance's ball in world space first: a ray that passes it by, or has it behind, needs neither the
+                // instance's matrix nor the object-space set-up (three divisions and a dozen loads)
+                // (for the candidates only: what the top-level tree hands out has passed its box already, and the extra
+                // dependent load in front of every instance costs a scene with many of those more than it saves)
+                bool reach = instance != own_instance;
+                if (reach && first >= sv.sun_cand_base) {
+                    const float4 wb = sv.world_ball[instance];
+                    if (wb.w > 0.0f) {
+                        const vec3 oc = mk3(o.x - wb.x, o.y - wb.y, o.z - wb.z);
+                        const float a = dot3(d, d), b = dot3(oc, d), cc = dot3(oc, oc) - wb.w * wb.w;
+                        reach = !(b * b - a * cc < 0.0f) && !(b > 0.0f && cc > 0.0f);
+                    }
+                }
+                if (reach) {
                     const GpuInstance& inst = sv.instances[instance];
                     ray = object_ray(inst, o, d, tmax);
                     const BallVerdict v = ball_verdict(sv.instance_ball[instance], inst.outer_radius, ray.o, ray.d, tmin, tmax, t_hi);
@@ -295,7 +318,6 @@ RDR_DEV bool shadow_any_hit(const SceneView& sv, uint32_t own_instance, bool ski
         if (hit) break;
         if (cur == kBvhNone) {
             if (st.sp == floor) { // this instance is done: back to the world ray
-                if (mode == kTraceOwn) break;
                 t_hi = tmax;
                 floor = -1;
                 ray = make_ray(o, d, tmax);
@@ -336,6 +358,79 @@ RDR_DEV bool leaves_convex_mesh(const SceneView& sv, uint32_t draw_id, uint32_t 
     if (c == 0.0f || lod != 0u) return false;
     const float out = c > 0.0f ? dot3(face_normal, L) : -dot3(face_normal, L);
     return out > fabsf(c) * len3(face_normal);
+}
+
+// Which instances can block a sun ray that starts on a given instance: one thread per draw sends a fat ray from
+// the centre of the instance's ball towards the sun through the top level -- every box widened by the world-space
+// radius that holds all of the instance's vertices, which covers every ray that starts on the instance -- and
+// collects the other instances in the leaves it reaches.  The boxes bound the instances' geometry, so a triangle of
+// an instance that is not collected cannot be hit.  Up to kSunCandidates are kept (more, or a stack overflow: the
+// shadow rays walk the top level as before).  Depends on the sun direction and the transforms only: launched
+// when either has changed (rdr_shade), not per frame.
+__global__ __launch_bounds__(256) void k_sun_candidates(SceneView sv, FrameView fv) {
+    __shared__ uint32_t stack_mem[(kLdsStack + 1) * 256];
+    const uint32_t di = blockIdx.x * 256u + threadIdx.x;
+    if (di >= sv.draw_count) return;
+    const float reach = sv.instance_reach[di];
+    uint32_t count = 255u;
+    float4 wball = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (reach > 0.0f) {
+        const float4 ball = sv.instance_ball[di];
+        float model[16];
+        load_m4(sv.transforms + (size_t)sv.draws[di].model_index * 16, model);
+        const vec4 cw = mul_m4(model, mk4(ball.x, ball.y, ball.z, 1.0f));
+        const vec3 c = mk3(cw.x, cw.y, cw.z);
+        {
+            // the ball around the mesh the ray structure holds, in world space (for the pre-test in front of an instance's walk)
+            const float r0 = sv.instances[di].outer_radius * model_max_scale(model) * 1.001f + 1e-5f * (1.0f + fmaxf(fabsf(c.x), fmaxf(fabsf(c.y), fabsf(c.z))));
+            if (r0 > 0.0f && r0 < 1e30f) wball = make_float4(c.x, c.y, c.z, r0);
+        }
+      if (fv.sun_candidates) {
+        // world-space radius with room for the rounding of an origin (interpolated world position) and of this sum
+        const float R = reach * model_max_scale(model) * 1.001f + 1e-4f * (1.0f + fmaxf(fabsf(c.x), fmaxf(fabsf(c.y), fabsf(c.z))));
+        const vec3 L = normalize3(mk3(fv.ubo.sun_direction[0], fv.ubo.sun_direction[1], fv.ubo.sun_direction[2]));
+        Ray ray = make_ray(c, L, kShadowTmax + R);
+        // widening every box by R is moving the entry planes R / |d| earlier and the exit planes as much later
+        const vec3 w = mk3(R * fabsf(ray.slab.inv_d.x), R * fabsf(ray.slab.inv_d.y), R * fabsf(ray.slab.inv_d.z));
+        ray.slab.c_near = ray.slab.c_near - w;
+        ray.slab.c_far = ray.slab.c_far + w;
+        LdsStack st;
+        st.base = stack_mem + threadIdx.x;
+        st.limit = kLdsStack;
+        st.sp = 0;
+        st.overflow = false;
+        bool give_up = !(R < 1e30f) || !(L.x == L.x); // a radius or a direction that is not a number proves nothing
+        uint32_t n = 0, cur = 0u;
+        uint32_t* out = sv.sun_cand_items + (size_t)di * kSunCandidates;
+        while (!give_up) {
+            if (!(cur & kBvhLeaf)) {
+                const uint4* q = reinterpret_cast<const uint4*>(sv.bvh + (sv.tlas_base + cur));
+                const uint4 codes = q[0], bx = q[1], by = q[2], bz = q[3];
+                const uint32_t code[4] = {codes.x, codes.y, codes.z, codes.w};
+                const uint32_t wx[4] = {bx.x, bx.y, bx.z, bx.w}, wy[4] = {by.x, by.y, by.z, by.w}, wz[4] = {bz.x, bz.y, bz.z, bz.w};
+#pragma unroll
+                for (int i = 0; i < kBvhWidth; ++i) {
+                    float t_exit;
+                    st.push_if((code[i] != kBvhNone) & ray_box(wx[i], wy[i], wz[i], ray.slab, -R, kShadowTmax + R, t_exit), code[i]);
+                }
+            } else {
+                const uint32_t items = (cur >> 24) & 127u, first = cur & 0xFFFFFFu;
+                for (uint32_t i = 0; i < items; ++i) {
+                    const uint32_t other = sv.tlas_items[first + i];
+                    if (other == di) continue;
+                    if (n < kSunCandidates) out[n] = other;
+                    ++n;
+                }
+            }
+            if (st.sp == 0 || n > kSunCandidates) break;
+            cur = st.pop();
+        }
+        // (a top-level leaf code holds its first item in 24 bits)
+        if (!give_up && !st.overflow && n <= kSunCandidates && sv.sun_cand_base + (di + 1u) * kSunCandidates < (1u << 24)) count = n;
+      }
+    }
+    sv.sun_cand_count[di] = (uint8_t)count;
+    sv.world_ball[di] = wball;
 }
 
 // Pass 0: classification.  A workgroup of sixteen waves owns a 128x128-pixel region as four 64x64
@@ -428,9 +523,8 @@ RDR_DEV ShadowRay shadow_ray_of(const SceneView& sv, const FrameView& fv, uint32
     r.skip_own = (fv.convex_skip & 1u) && leaves_convex_mesh(sv, p.draw_id, p.lod, face_normal, r.d);
     return r;
 }
-constexpr float kShadowTmin = 1e-2f, kShadowTmax = 1000.0f;
 
-__global__ __launch_bounds__(256) void k_shadow(SceneView sv, FrameView fv) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_shadow(SceneView sv, FrameView fv) {
     __shared__ uint32_t stack_mem[(kLdsStack + 1) * 256];
     const uint32_t entry = blockIdx.x * 256u + threadIdx.x;
     if (entry >= fv.counters->pixel_count) return;
@@ -498,6 +592,13 @@ __global__ __launch_bounds__(256) void k_shadow_walk(SceneView sv, FrameView fv)
 }
 
 } // namespace
+
+int rdr_launch_sun_candidates(const SceneView& sv, const FrameView& fv, hipStream_t stream) {
+    if (sv.draw_count == 0) return 0;
+    hipLaunchKernelGGL(k_sun_candidates, dim3((sv.draw_count + 255u) / 256u), dim3(256), 0, stream, sv, fv);
+    RDR_HIP(hipGetLastError());
+    return 0;
+}
 
 int rdr_launch_shadow(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev) {
     if (fv.row_hi <= fv.row_lo) return 0;

@@ -213,6 +213,44 @@ def test_shadow_walk_kernel_equals_inline_walk(monkeypatch, lods, stack):
     assert covered(frames["1"][0]).sum() > 20000
 
 
+def test_sun_candidates_follow_sun_and_transforms(oracle, monkeypatch):
+    """The per-instance lists of possible sun occluders are rebuilt when the sun direction or the transforms
+    change: frames under a low sun (long shadows across neighbours), a high sun, the low sun again and moved
+    instances all match the CPU check, and match the frames rendered with the lists switched off."""
+    sc = synth.make_field(200, 3, lods=1, with_env=True, prepared=True)
+    w, h = 480, 270
+    conf = RendererConfig(lod_enabled=False, cull_enabled=False)
+    suns = [(0.9, 0.25, 0.2), (-0.23623444, 0.9302103, 0.2808959), (0.9, 0.25, 0.2), (-0.3, 0.2, 0.9)]
+    o = oracle.OracleRenderer(w, h, conf)
+    o.set_scene(sc)
+    g = Renderer(w, h, conf)
+    g.set_scene(sc)
+    monkeypatch.setenv("RDR_SUN_CANDIDATES", "0")
+    plain = Renderer(w, h, conf)
+    monkeypatch.delenv("RDR_SUN_CANDIDATES")
+    plain.set_scene(sc)
+    shadowed = []
+    for k, sun in enumerate(suns):
+        if k == 3:  # move every other instance up and sideways: the lists of the third frame no longer hold
+            t = np.array(sc.global_transforms, dtype=np.float32).reshape(-1, 16).copy()
+            t[::2, 12] += 0.8
+            t[::2, 13] += 1.1
+            sc.global_transforms = t
+            o.set_scene(sc)
+            g.update_transforms(t)
+            plain.update_transforms(t)
+        ovis = o.render_visbuffer(sun=sun)
+        g.render(sun=sun)
+        plain.render(sun=sun)
+        assert np.array_equal(g.read_visbuffer_u64(), ovis)
+        check_color(o, g)
+        assert np.array_equal(g.read_color(), plain.read_color())
+        shadowed.append(g.read_color().copy())
+    assert np.array_equal(shadowed[0], shadowed[2]) and not np.array_equal(shadowed[0], shadowed[1])
+    g.close()
+    plain.close()
+
+
 def test_known_answer_triangle():
     W = H = 64
     sc = fb_triangle_scene([[(8, 8, 5.0), (8, 40, 5.0), (40, 8, 5.0)]], W, H)
