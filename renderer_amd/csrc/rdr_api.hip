@@ -366,7 +366,8 @@ int upload_tlas(rdr_renderer* r) {
     }
     if (r->instances.upload(r->bvh.instances.data(), r->bvh.instances.size())) return 1;
     if (const char* e = std::getenv("RDR_INNER_BALL")) // measurement hook: 0 = no instance has an inner ball
-        if (std::atoi(e) == 0) std::fill(r->bvh.instance_ball.begin(), r->bvh.instance_ball.end(), 0.0f);
+        if (std::atoi(e) == 0)
+            for (size_t i = 3; i < r->bvh.instance_ball.size(); i += 4) r->bvh.instance_ball[i] = 0.0f; // the radius only: the centre also serves the outer ball
     if (r->instance_ball.upload(reinterpret_cast<const float4*>(r->bvh.instance_ball.data()), r->bvh.instance_ball.size() / 4)) return 1;
     r->sv.bvh = r->bvh_dev.ptr;
     r->sv.tlas_base = (uint32_t)blas_count;
