@@ -415,6 +415,14 @@ FrameView make_frame_view(rdr_renderer* r) {
     fv.lds_stack_limit = r->lds_stack_limit;
     fv.convex_skip = r->convex_skip;
     fv.shadow_defer = r->shadow_defer;
+    {
+        // normalize3() and div_exact() of rdr_device.h / rdr_pixel.h, term for term (this file is built without contraction too)
+        const float x = fv.ubo.sun_direction[0], y = fv.ubo.sun_direction[1], z = fv.ubo.sun_direction[2];
+        const float l = std::sqrt((x * x + y * y) + z * z);
+        fv.sun_unit[0] = x / l; fv.sun_unit[1] = y / l; fv.sun_unit[2] = z / l;
+        fv.two_over_width = 2.0f / fv.ubo.screen_width;
+        fv.two_over_height = 2.0f / fv.ubo.screen_height;
+    }
     fv.sun_candidates = r->sun_candidates;
     fv.host_status = r->status_dev;
     fv.frame_seq = r->frame_seq & 0xFFFFFFu;

@@ -349,7 +349,7 @@ struct FrameView {
     uint32_t row_lo, row_hi;
     uint32_t command_capacity, visible_capacity, deferred_capacity;
     uint32_t collect_stats;
-    uint32_t* pixel_list; // indices of the covered pixels in the shaded rows (k_classify)
+    uint32_t* pixel_list; // the covered pixels of the shaded rows (k_classify), as y << 16 | x
     uint32_t* pixel_key;  // per pixel_list entry: the low word of the pixel's key, (instance << 7) | triangle
     uint8_t* shadow;      // one byte per pixel_list entry: 1 = the sun ray is blocked (padded to a multiple of 16 bytes)
     SetupTri* setup;
@@ -398,6 +398,10 @@ struct FrameView {
     uint32_t frame_seq;
     uint32_t convex_skip; // 1: shadow rays that leave a closed convex mesh skip that mesh (0 only as a measurement hook)
     uint32_t sun_candidates; // 1: SceneView::sun_cand_* hold this frame's sun direction and transforms (0 only as a measurement hook)
+    // Per-frame values that are the same in every lane, worked out once on the host with the arithmetic the kernels
+    // would use (same expressions, same rounding): the normalised sun direction and 2 / width, 2 / height.
+    float sun_unit[3];
+    float two_over_width, two_over_height;
     uint32_t shadow_defer; // 1: walks through a ray's own closed convex instance are left to k_shadow_walk (0 only as a measurement hook)
     // Per-workgroup statistics: every workgroup stores its partial counts in its own
     // slot with plain stores (no contended atomics); the host sums the slots on request.

@@ -34,7 +34,8 @@ RDR_DEV float div_exact(float a, float b) {
 RDR_DEV float div_exact(float a, float b) { return a / b; }
 #endif
 
-RDR_DEV BaryDeriv calc_full_bary(vec4 pt0, vec4 pt1, vec4 pt2, float ndcx, float ndcy, float winw, float winh) {
+// `sx`, `sy`: 2 / window width, 2 / window height (correctly rounded)
+RDR_DEV BaryDeriv calc_full_bary(vec4 pt0, vec4 pt1, vec4 pt2, float ndcx, float ndcy, float sx, float sy) {
     BaryDeriv r;
     const vec3 inv_w = mk3(div_exact(1.0f, pt0.w), div_exact(1.0f, pt1.w), div_exact(1.0f, pt2.w));
     const float n0x = pt0.x * inv_w.x, n0y = pt0.y * inv_w.x;
@@ -52,7 +53,6 @@ RDR_DEV BaryDeriv calc_full_bary(vec4 pt0, vec4 pt1, vec4 pt2, float ndcx, float
     r.lambda.x = interp_w * ((inv_w.x + dx * r.ddx.x) + dy * r.ddy.x);
     r.lambda.y = interp_w * ((0.0f + dx * r.ddx.y) + dy * r.ddy.y);
     r.lambda.z = interp_w * ((0.0f + dx * r.ddx.z) + dy * r.ddy.z);
-    const float sx = div_exact(2.0f, winw), sy = div_exact(2.0f, winh);
     r.ddx = r.ddx * sx;
     r.ddy = r.ddy * sy;
     ddx_sum *= sx;
@@ -104,7 +104,8 @@ RDR_DEV ListedPixel listed_pixel(const SceneView& sv, const FrameView& fv, uint3
     p.model_index = df.model_index;
     p.material_index = df.material_lod & 0xFFFFu;
     p.lod = df.material_lod >> 16;
-    const uint32_t iy = p.pi / fv.width, ix = p.pi - iy * fv.width;
+    const uint32_t packed = p.pi, iy = packed >> 16, ix = packed & 0xFFFFu;
+    p.pi = iy * fv.width + ix;
     p.uvx = ((float)ix + 0.5f) / (float)fv.width;
     p.uvy = 1.0f - ((float)iy + 0.5f) / (float)fv.height;
     return p;

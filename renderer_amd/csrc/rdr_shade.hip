@@ -157,7 +157,8 @@ RDR_DEV uint32_t srgb_encode(float c) {
 }
 
 // `srgb`: the sRGB decode table (SceneView::srgb_lut or a copy of it)
-RDR_DEV vec3 shade_pixel(const SceneView& sv, const float* srgb, const rdr_ubo& u, const ListedPixel& px, bool shadow_hit) {
+RDR_DEV vec3 shade_pixel(const SceneView& sv, const float* srgb, const FrameView& fv, const ListedPixel& px, bool shadow_hit) {
+    const rdr_ubo& u = fv.ubo;
     const float uvx = px.uvx, uvy = px.uvy;
     float model[16];
     load_m4(sv.transforms + (size_t)px.model_index * 16, model);
@@ -172,7 +173,7 @@ RDR_DEV vec3 shade_pixel(const SceneView& sv, const float* srgb, const rdr_ubo& 
     const vec4 w2 = mul_m4(model, mk4(v2->p[0], v2->p[1], v2->p[2], 1.0f));
     const vec4 w3 = mul_m4(model, mk4(v3->p[0], v3->p[1], v3->p[2], 1.0f));
     const vec4 c1 = mul_m4(u.view_proj, w1), c2 = mul_m4(u.view_proj, w2), c3 = mul_m4(u.view_proj, w3);
-    const BaryDeriv bary = calc_full_bary(c1, c2, c3, uvx * 2.0f - 1.0f, uvy * 2.0f - 1.0f, u.screen_width, u.screen_height);
+    const BaryDeriv bary = calc_full_bary(c1, c2, c3, uvx * 2.0f - 1.0f, uvy * 2.0f - 1.0f, fv.two_over_width, fv.two_over_height);
 
     const vec3 w_pos = interp3(bary, mk3(w1.x, w1.y, w1.z), mk3(w2.x, w2.y, w2.z), mk3(w3.x, w3.y, w3.z));
     const vec3 norm = interp3(bary, mul_m3(model, vload3(v1->n)), mul_m3(model, vload3(v2->n)), mul_m3(model, vload3(v3->n)));
@@ -212,7 +213,7 @@ RDR_DEV vec3 shade_pixel(const SceneView& sv, const float* srgb, const rdr_ubo& 
     const vec3 bitangent = cross3(nnormal, ntangent) * ((v1->t[3] * v2->t[3]) * v3->t[3]);
     const vec3 nrm = normalize3((ntangent * nmap.x + bitangent * nmap.y) + nnormal * nmap.z);
 
-    const vec3 L = normalize3(mk3(u.sun_direction[0], u.sun_direction[1], u.sun_direction[2]));
+    const vec3 L = mk3(fv.sun_unit[0], fv.sun_unit[1], fv.sun_unit[2]);
 
     const float metallic = clampf(mat.metallic_roughness_normal_occlusion[0] * mr.z, 0.0f, 1.0f);
     float prough = mr.y * mat.metallic_roughness_normal_occlusion[1];
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __syncthreads();
     if (entry >= count) return;
     const ListedPixel p = listed_pixel(sv, fv, entry);
-    const vec3 c = shade_pixel(sv, lut, fv.ubo, p, fv.shadow[entry] != 0);
+    const vec3 c = shade_pixel(sv, lut, fv, p, fv.shadow[entry] != 0);
     reinterpret_cast<uint32_t*>(fv.color)[p.pi] =
         srgb_encode(c.x) | (srgb_encode(c.y) << 8) | (srgb_encode(c.z) << 16) | (255u << 24);
 }

@@ -332,7 +332,7 @@ RDR_DEV bool shadow_any_hit(const SceneView& sv, uint32_t own_instance, bool ski
 
 // World-space position of the surface point seen through a pixel (the shadow ray's origin).
 // `face_normal`: (w2 - w1) x (w3 - w1) of the pixel's triangle in world space, not normalised.
-RDR_DEV vec3 pixel_world_position(const SceneView& sv, const rdr_ubo& u, const ListedPixel& p, vec3& face_normal) {
+RDR_DEV vec3 pixel_world_position(const SceneView& sv, const rdr_ubo& u, float two_over_width, float two_over_height, const ListedPixel& p, vec3& face_normal) {
     float model[16];
     load_m4(sv.transforms + (size_t)p.model_index * 16, model);
     // positions from the 64-byte vertices (one 12-byte load and one cache line per vertex, the line the shading pass
@@ -344,7 +344,7 @@ RDR_DEV vec3 pixel_world_position(const SceneView& sv, const rdr_ubo& u, const L
     const vec4 w2 = mul_m4(model, mk4(q2[0], q2[1], q2[2], 1.0f));
     const vec4 w3 = mul_m4(model, mk4(q3[0], q3[1], q3[2], 1.0f));
     const vec4 c1 = mul_m4(u.view_proj, w1), c2 = mul_m4(u.view_proj, w2), c3 = mul_m4(u.view_proj, w3);
-    const BaryDeriv bary = calc_full_bary(c1, c2, c3, p.uvx * 2.0f - 1.0f, p.uvy * 2.0f - 1.0f, u.screen_width, u.screen_height);
+    const BaryDeriv bary = calc_full_bary(c1, c2, c3, p.uvx * 2.0f - 1.0f, p.uvy * 2.0f - 1.0f, two_over_width, two_over_height);
     face_normal = cross3(mk3(w2.x - w1.x, w2.y - w1.y, w2.z - w1.z), mk3(w3.x - w1.x, w3.y - w1.y, w3.z - w1.z));
     return interp3(bary, mk3(w1.x, w1.y, w1.z), mk3(w2.x, w2.y, w2.z), mk3(w3.x, w3.y, w3.z));
 }
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void k_sun_candidates(SceneView sv, FrameView 
       if (fv.sun_candidates) {
         // world-space radius with room for the rounding of an origin (interpolated world position) and of this sum
         const float R = reach * model_max_scale(model) * 1.001f + 1e-4f * (1.0f + fmaxf(fabsf(c.x), fmaxf(fabsf(c.y), fabsf(c.z))));
-        const vec3 L = normalize3(mk3(fv.ubo.sun_direction[0], fv.ubo.sun_direction[1], fv.ubo.sun_direction[2]));
+        const vec3 L = mk3(fv.sun_unit[0], fv.sun_unit[1], fv.sun_unit[2]);
         Ray ray = make_ray(c, L, kShadowTmax + R);
         // widening every box by R is moving the entry planes R / |d| earlier and the exit planes as much later
         const vec3 w = mk3(R * fabsf(ray.slab.inv_d.x), R * fabsf(ray.slab.inv_d.y), R * fabsf(ray.slab.inv_d.z));
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(1024) void k_classify(FrameView fv) {
         if (covered) {
             const uint32_t ix = x0 + (b & 3u) * 16, iy = y0 + (b >> 2) * 16;
             const uint32_t at = base + wave_count[quad * 64 + b * 4 + wave] + ballot_rank(m);
-            fv.pixel_list[at] = iy * fv.width + ix;
+            fv.pixel_list[at] = (iy << 16) | ix;
             fv.pixel_key[at] = ids[b];
         }
     }
@@ -517,8 +517,8 @@ RDR_DEV ShadowRay shadow_ray_of(const SceneView& sv, const FrameView& fv, uint32
     const ListedPixel p = listed_pixel(sv, fv, entry);
     vec3 face_normal;
     ShadowRay r;
-    r.o = pixel_world_position(sv, fv.ubo, p, face_normal);
-    r.d = normalize3(mk3(fv.ubo.sun_direction[0], fv.ubo.sun_direction[1], fv.ubo.sun_direction[2]));
+    r.o = pixel_world_position(sv, fv.ubo, fv.two_over_width, fv.two_over_height, p, face_normal);
+    r.d = mk3(fv.sun_unit[0], fv.sun_unit[1], fv.sun_unit[2]);
     r.draw_id = p.draw_id;
     r.skip_own = (fv.convex_skip & 1u) && leaves_convex_mesh(sv, p.draw_id, p.lod, face_normal, r.d);
     return r;
