@@ -270,6 +270,7 @@ int validate_scene(const rdr_scene_desc& s) {
         const rdr_image_desc& im = s.images[i];
         if (!im.data) continue;
         RDR_CHECK(im.width && im.height && im.mip_count >= 1 && im.mip_count <= 17, "scene: image dimensions / mip count invalid");
+        RDR_CHECK(im.width <= 32768 && im.height <= 32768, "scene: image larger than 32768 x 32768 (the sampler indexes a level's texels with 31 bits)");
         RDR_CHECK(im.format <= RDR_FORMAT_BC4, "scene: unknown image format");
     }
     return 0;
@@ -337,7 +338,7 @@ int pack_cubemap(TexelPacker& tp, const rdr_cubemap_desc* cm, GpuCubemap* out) {
         *out = g;
         return 0;
     }
-    RDR_CHECK(cm->size && cm->mip_count >= 1 && cm->mip_count <= 17, "scene: cubemap dimensions / mip count invalid");
+    RDR_CHECK(cm->size && cm->size <= 16384 && cm->mip_count >= 1 && cm->mip_count <= 17, "scene: cubemap dimensions / mip count invalid (faces of at most 16384 x 16384)");
     RDR_CHECK(cm->format == RDR_FORMAT_RGBA8_UNORM || cm->format == RDR_FORMAT_RGBA32F, "scene: cubemap format must be RGBA8_UNORM or RGBA32F");
     std::vector<uint8_t> padded;
     rdr_pack_cubemap(*cm, g, padded);
@@ -774,7 +775,7 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
         rdr_image_desc lut_desc{zero_lut, 1, 1, 1, RDR_FORMAT_RGBA32F};
         if (s.env && s.env->brdf_lut.data) {
             lut_desc = s.env->brdf_lut;
-            RDR_CHECK(lut_desc.width && lut_desc.height && lut_desc.mip_count >= 1 && lut_desc.mip_count <= 17 && lut_desc.format <= RDR_FORMAT_RGBA32F,
+            RDR_CHECK(lut_desc.width && lut_desc.height && lut_desc.width <= 32768 && lut_desc.height <= 32768 && lut_desc.mip_count >= 1 && lut_desc.mip_count <= 17 && lut_desc.format <= RDR_FORMAT_RGBA32F,
                       "scene: brdf_lut invalid");
         }
         r->sv.brdf_lut = pack_image(tp, lut_desc);

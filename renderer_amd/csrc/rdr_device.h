@@ -167,18 +167,19 @@ RDR_DEV vec4 image_bilinear(const GpuImage& im, const uint8_t* texels, const flo
     const int y0 = wrap_repeat((int)fy, h), y1 = wrap_repeat((int)fy + 1, h);
     vec4 t00, t10, t01, t11;
     if (im.format == RDR_FORMAT_RGBA32F) {
-        t00 = decode_texel(base + ((size_t)y0 * w + x0) * 16u, im.format, lut);
-        t10 = decode_texel(base + ((size_t)y0 * w + x1) * 16u, im.format, lut);
-        t01 = decode_texel(base + ((size_t)y1 * w + x0) * 16u, im.format, lut);
-        t11 = decode_texel(base + ((size_t)y1 * w + x1) * 16u, im.format, lut);
+        // texel indices fit 32 bits (a level has at most 16 384 x 16 384 texels); only the byte offset needs 64
+        t00 = decode_texel(base + ((size_t)(uint32_t)(y0 * w + x0) << 4), im.format, lut);
+        t10 = decode_texel(base + ((size_t)(uint32_t)(y0 * w + x1) << 4), im.format, lut);
+        t01 = decode_texel(base + ((size_t)(uint32_t)(y1 * w + x0) << 4), im.format, lut);
+        t11 = decode_texel(base + ((size_t)(uint32_t)(y1 * w + x1) << 4), im.format, lut);
     } else {
         // a footprint's two texels of a row are neighbours in memory unless it wraps around the last column:
         // four loads per tap become two, and the address unit is what the textured passes keep busiest
-        TexelPair r0 = load_texel_pair(base + ((size_t)y0 * w + x0) * 4u);
-        TexelPair r1 = load_texel_pair(base + ((size_t)y1 * w + x0) * 4u);
+        TexelPair r0 = load_texel_pair(base + ((size_t)(uint32_t)(y0 * w + x0) << 2));
+        TexelPair r1 = load_texel_pair(base + ((size_t)(uint32_t)(y1 * w + x0) << 2));
         if (x1 != x0 + 1) {
-            r0.b = *reinterpret_cast<const uint32_t*>(base + ((size_t)y0 * w + x1) * 4u);
-            r1.b = *reinterpret_cast<const uint32_t*>(base + ((size_t)y1 * w + x1) * 4u);
+            r0.b = *reinterpret_cast<const uint32_t*>(base + ((size_t)(uint32_t)(y0 * w + x1) << 2));
+            r1.b = *reinterpret_cast<const uint32_t*>(base + ((size_t)(uint32_t)(y1 * w + x1) << 2));
         }
         t00 = decode_rgba8(r0.a, im.format, lut); t10 = decode_rgba8(r0.b, im.format, lut);
         t01 = decode_rgba8(r1.a, im.format, lut); t11 = decode_rgba8(r1.b, im.format, lut);
@@ -243,13 +244,14 @@ RDR_DEV vec4 cube_bilinear(const GpuCubemap& cm, const uint8_t* texels, uint32_t
     // -1 .. n-1 for any finite direction; the clamp keeps a non-finite one inside the allocation
     const int i0 = min(max((int)fx, -1), n - 1), j0 = min(max((int)fy, -1), n - 1);
     const uint32_t tb = cm.format == RDR_FORMAT_RGBA32F ? 16u : 4u;
-    const size_t pitch = (size_t)(n + 2);
-    const uint8_t* p = texels + cm.offset + cm.level_offset[level] +
-                       (((size_t)face * pitch + (size_t)(j0 + 1)) * pitch + (size_t)(i0 + 1)) * tb;
+    const uint32_t pitch = (uint32_t)(n + 2);
+    // six faces of at most 16 386 x 16 386 bordered texels: the texel index fits 32 bits, the byte offset may not
+    const uint32_t texel = ((uint32_t)face * pitch + (uint32_t)(j0 + 1)) * pitch + (uint32_t)(i0 + 1);
+    const uint8_t* p = texels + cm.offset + cm.level_offset[level] + (size_t)texel * tb;
     const vec4 t00 = decode_texel(p, cm.format, nullptr);
     const vec4 t10 = decode_texel(p + tb, cm.format, nullptr);
-    const vec4 t01 = decode_texel(p + pitch * tb, cm.format, nullptr);
-    const vec4 t11 = decode_texel(p + pitch * tb + tb, cm.format, nullptr);
+    const vec4 t01 = decode_texel(p + (size_t)(pitch * tb), cm.format, nullptr);
+    const vec4 t11 = decode_texel(p + (size_t)(pitch * tb) + tb, cm.format, nullptr);
     return lerp4(lerp4(t00, t10, ax), lerp4(t01, t11, ax), ay);
 }
 
