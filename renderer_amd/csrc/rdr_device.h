@@ -137,10 +137,13 @@ RDR_DEV int wrap_repeat(int i, int n) {
     return m < 0 ? m + n : m;
 }
 
-RDR_DEV vec4 decode_rgba8(uint32_t t, uint32_t format, const float* srgb_lut) {
+// `lut`: 256 sRGB -> linear values; with `lut_linear` 256 more behind them, unorm8() of every byte (a table in LDS
+// then takes the place of three vector instructions per channel)
+RDR_DEV vec4 decode_rgba8(uint32_t t, uint32_t format, const float* lut, bool lut_linear = false) {
     const uint32_t r = t & 255u, g = (t >> 8) & 255u, b = (t >> 16) & 255u, a = t >> 24;
     if (format == RDR_FORMAT_RGBA8_SRGB)
-        return mk4(srgb_lut[r], srgb_lut[g], srgb_lut[b], unorm8(a));
+        return mk4(lut[r], lut[g], lut[b], lut_linear ? lut[256u + a] : unorm8(a));
+    if (lut_linear) return mk4(lut[256u + r], lut[256u + g], lut[256u + b], lut[256u + a]);
     return mk4(unorm8(r), unorm8(g), unorm8(b), unorm8(a));
 }
 
@@ -157,7 +160,7 @@ RDR_DEV TexelPair load_texel_pair(const uint8_t* p) {
 }
 
 RDR_DEV vec4 image_bilinear(const GpuImage& im, const uint8_t* texels, const float* lut, uint32_t level,
-                            float u, float v) {
+                            float u, float v, bool lut_linear = false) {
     const int w = (int)mip_dim(im.width, level), h = (int)mip_dim(im.height, level);
     const uint8_t* base = texels + im.offset + im.level_offset[level];
     const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
@@ -181,14 +184,14 @@ RDR_DEV vec4 image_bilinear(const GpuImage& im, const uint8_t* texels, const flo
             r0.b = *reinterpret_cast<const uint32_t*>(base + ((size_t)(uint32_t)(y0 * w + x1) << 2));
             r1.b = *reinterpret_cast<const uint32_t*>(base + ((size_t)(uint32_t)(y1 * w + x1) << 2));
         }
-        t00 = decode_rgba8(r0.a, im.format, lut); t10 = decode_rgba8(r0.b, im.format, lut);
-        t01 = decode_rgba8(r1.a, im.format, lut); t11 = decode_rgba8(r1.b, im.format, lut);
+        t00 = decode_rgba8(r0.a, im.format, lut, lut_linear); t10 = decode_rgba8(r0.b, im.format, lut, lut_linear);
+        t01 = decode_rgba8(r1.a, im.format, lut, lut_linear); t11 = decode_rgba8(r1.b, im.format, lut, lut_linear);
     }
     return lerp4(lerp4(t00, t10, ax), lerp4(t01, t11, ax), ay);
 }
 
 RDR_DEV vec4 image_sample_lod(const GpuImage& im, const uint8_t* texels, const float* lut, float u, float v,
-                              float lod) {
+                              float lod, bool lut_linear = false) {
     float maxl = (float)(im.mip_count - 1);
     if (maxl > 16.0f) maxl = 16.0f;
     if (!(lod > 0.0f)) lod = 0.0f;
@@ -197,19 +200,19 @@ RDR_DEV vec4 image_sample_lod(const GpuImage& im, const uint8_t* texels, const f
     const uint32_t l0 = (uint32_t)fl;
     const uint32_t l1 = l0 + 1 < im.mip_count ? l0 + 1 : l0;
     const float t = lod - fl;
-    const vec4 a = image_bilinear(im, texels, lut, l0, u, v);
+    const vec4 a = image_bilinear(im, texels, lut, l0, u, v, lut_linear);
     if (l1 == l0 || t == 0.0f) return a;
-    const vec4 b = image_bilinear(im, texels, lut, l1, u, v);
+    const vec4 b = image_bilinear(im, texels, lut, l1, u, v, lut_linear);
     return lerp4(a, b, t);
 }
 
 RDR_DEV vec4 image_sample_grad(const GpuImage& im, const uint8_t* texels, const float* lut, float u, float v,
-                               float dudx, float dvdx, float dudy, float dvdy) {
+                               float dudx, float dvdx, float dudy, float dvdy, bool lut_linear = false) {
     const float w = (float)im.width, h = (float)im.height;
     const float ax = dudx * w, ay = dvdx * h, bx = dudy * w, by = dvdy * h;
     // max(sqrt(a), sqrt(b)) == sqrt(max(a, b)): the correctly rounded square root is monotonic
     const float rho = sqrtf(fmaxf(ax * ax + ay * ay, bx * bx + by * by));
-    return image_sample_lod(im, texels, lut, u, v, log2f(rho));
+    return image_sample_lod(im, texels, lut, u, v, log2f(rho), lut_linear);
 }
 
 // ---- cubemaps ------------------------------------------------------------------

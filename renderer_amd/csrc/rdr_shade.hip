@@ -32,7 +32,7 @@ RDR_DEV InterpUv uv_transform(InterpUv in, float sx, float sy, float ox, float o
 RDR_DEV vec4 sample_or_default(const SceneView& sv, const float* lut, uint32_t tex, InterpUv uv, vec4 def) {
     if (tex == RDR_NO_TEXTURE) return def;
     if (tex >= sv.image_count || sv.images[tex].mip_count == 0u) return mk4(0.0f, 0.0f, 0.0f, 0.0f);
-    return image_sample_grad(sv.images[tex], sv.texels, lut, uv.u, uv.v, uv.dudx, uv.dvdx, uv.dudy, uv.dvdy);
+    return image_sample_grad(sv.images[tex], sv.texels, lut, uv.u, uv.v, uv.dudx, uv.dvdx, uv.dudy, uv.dvdy, true);
 }
 
 // ---- BRDF terms -------------------------------------------------------------------
@@ -293,7 +293,7 @@ RDR_DEV vec3 shade_pixel(const SceneView& sv, const float* srgb, const FrameView
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_shade(SceneView sv, FrameView fv) {
     // the sRGB decode table in LDS: a trilinear tap of an sRGB texture looks up 24 values, each a dependent load
     // behind its texel if the table stays in memory
-    __shared__ float lut[256];
+    __shared__ float lut[512]; // and unorm8() of every byte behind it
     const uint32_t entry = blockIdx.x * 256u + threadIdx.x;
     if (entry == 0u) // last kernel of the shading half that every frame runs: the frame's status for the host
         __hip_atomic_store(&fv.host_status[1], (fv.frame_seq << 8) | (fv.counters->deep_overflow ? RDR_FRAME_SHADOW_STACK : 0u),
@@ -301,6 +301,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint32_t count = fv.counters->pixel_count;
     if (blockIdx.x * 256u >= count) return; // the whole workgroup
     lut[threadIdx.x] = sv.srgb_lut[threadIdx.x];
+    lut[256u + threadIdx.x] = unorm8(threadIdx.x);
     __syncthreads();
     if (entry >= count) return;
     const ListedPixel p = listed_pixel(sv, fv, entry);
