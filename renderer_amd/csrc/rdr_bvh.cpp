@@ -550,7 +550,15 @@ void rdr_build_tlas(const rdr_scene_desc& s, const float* transforms, HostBvh& i
             const double det = (double)m[0] * ((double)m[5] * m[10] - (double)m[6] * m[9]) - (double)m[4] * ((double)m[1] * m[10] - (double)m[2] * m[9]) +
                                (double)m[8] * ((double)m[1] * m[6] - (double)m[2] * m[5]);
             double scale = 0.0, M = 0.0;
-            for (int c = 0; c < 3; ++c) scale = std::max(scale, std::sqrt((double)m[4 * c] * m[4 * c] + (double)m[4 * c + 1] * m[4 * c + 1] + (double)m[4 * c + 2] * m[4 * c + 2]));
+            {
+                // how far the matrix can stretch a vector, from above (largest absolute row sum of A^T A; the longest
+                // column is a lower bound once the matrix shears)
+                double g[3][3];
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b)
+                        g[a][b] = std::fabs((double)m[4 * a] * m[4 * b] + (double)m[4 * a + 1] * m[4 * b + 1] + (double)m[4 * a + 2] * m[4 * b + 2]);
+                for (int a = 0; a < 3; ++a) scale = std::max(scale, std::sqrt(g[a][0] + g[a][1] + g[a][2]));
+            }
             for (int k = 0; k < 3; ++k) M = std::max(M, std::max(std::fabs((double)it.box.lo[k]), std::fabs((double)it.box.hi[k])));
             const double cos_min = std::max(0.01, (16.0 * 1.1920929e-7 * M + 4.0 * io.mesh_protrusion[d.mesh_index] * scale) / 0.01);
             if (det != 0.0 && std::isfinite(det) && cos_min < 0.95)

@@ -360,6 +360,16 @@ RDR_DEV bool leaves_convex_mesh(const SceneView& sv, uint32_t draw_id, uint32_t 
     return out > fabsf(c) * len3(face_normal);
 }
 
+// How far the 3 x 3 part of a model matrix can stretch a vector, from above: the square root of the largest absolute
+// row sum of A^T A (Gershgorin), which for a rotation times a uniform scale is the scale itself.  The longest column
+// (what the culling's bounding spheres use, as the reference does) is a lower bound once the matrix shears.
+RDR_DEV float model_stretch_bound(const float* m) {
+    const vec3 a0 = mk3(m[0], m[1], m[2]), a1 = mk3(m[4], m[5], m[6]), a2 = mk3(m[8], m[9], m[10]);
+    const float g00 = dot3(a0, a0), g11 = dot3(a1, a1), g22 = dot3(a2, a2);
+    const float g01 = fabsf(dot3(a0, a1)), g02 = fabsf(dot3(a0, a2)), g12 = fabsf(dot3(a1, a2));
+    return sqrtf(fmaxf(g00 + g01 + g02, fmaxf(g01 + g11 + g12, g02 + g12 + g22)));
+}
+
 // Which instances can block a sun ray that starts on a given instance: one thread per draw sends a fat ray from
 // the centre of the instance's ball towards the sun through the top level -- every box widened by the world-space
 // radius that holds all of the instance's vertices, which covers every ray that starts on the instance -- and
@@ -382,12 +392,12 @@ __global__ __launch_bounds__(256) void k_sun_candidates(SceneView sv, FrameView 
         const vec3 c = mk3(cw.x, cw.y, cw.z);
         {
             // the ball around the mesh the ray structure holds, in world space (for the pre-test in front of an instance's walk)
-            const float r0 = sv.instances[di].outer_radius * model_max_scale(model) * 1.001f + 1e-5f * (1.0f + fmaxf(fabsf(c.x), fmaxf(fabsf(c.y), fabsf(c.z))));
+            const float r0 = sv.instances[di].outer_radius * model_stretch_bound(model) * 1.001f + 1e-5f * (1.0f + fmaxf(fabsf(c.x), fmaxf(fabsf(c.y), fabsf(c.z))));
             if (r0 > 0.0f && r0 < 1e30f) wball = make_float4(c.x, c.y, c.z, r0);
         }
       if (fv.sun_candidates) {
         // world-space radius with room for the rounding of an origin (interpolated world position) and of this sum
-        const float R = reach * model_max_scale(model) * 1.001f + 1e-4f * (1.0f + fmaxf(fabsf(c.x), fmaxf(fabsf(c.y), fabsf(c.z))));
+        const float R = reach * model_stretch_bound(model) * 1.001f + 1e-4f * (1.0f + fmaxf(fabsf(c.x), fmaxf(fabsf(c.y), fabsf(c.z))));
         const vec3 L = mk3(fv.sun_unit[0], fv.sun_unit[1], fv.sun_unit[2]);
         Ray ray = make_ray(c, L, kShadowTmax + R);
         // widening every box by R is moving the entry planes R / |d| earlier and the exit planes as much later

@@ -251,6 +251,43 @@ def test_sun_candidates_follow_sun_and_transforms(oracle, monkeypatch):
     plain.close()
 
 
+def test_sun_candidates_under_sheared_instances(oracle, monkeypatch):
+    """Instances under shearing, non-uniformly scaling transforms shadow each other: the world-space radii behind the
+    occluder lists have to bound what such a matrix does to the mesh (its longest column does not)."""
+    rng = np.random.default_rng(5)
+    sc = synth.make_field(1, 3, lods=1, with_env=True, prepared=True)  # one sphere mesh, material and environment
+    mesh = 0
+    for k in range(60):
+        m = np.eye(4, dtype=np.float32)
+        m[:3, :3] = np.diag(rng.uniform(0.2, 1.0, 3)).astype(np.float32)
+        shear = np.eye(3, dtype=np.float32)
+        shear[0, 1], shear[0, 2], shear[1, 2] = rng.uniform(-1.5, 1.5, 3)
+        m[:3, :3] = shear @ m[:3, :3]
+        m[:3, 3] = (rng.uniform(-6, 6), rng.uniform(0.0, 4.0), rng.uniform(-6, 6))
+        sc.add_draw(mesh, m.T.reshape(16), 0)  # column-major
+    w, h = 480, 270
+    conf = RendererConfig(lod_enabled=False, cull_enabled=False)
+    cam = Camera((0.0, 4.0, 14.0), (0.0, 0.2, 1.0))
+    o = oracle.OracleRenderer(w, h, conf)
+    o.set_scene(sc)
+    g = Renderer(w, h, conf)
+    g.set_scene(sc)
+    monkeypatch.setenv("RDR_SUN_CANDIDATES", "0")
+    plain = Renderer(w, h, conf)
+    monkeypatch.delenv("RDR_SUN_CANDIDATES")
+    plain.set_scene(sc)
+    for sun in [(0.6, 0.5, 0.3), (-0.2, 0.9, -0.3)]:
+        ovis = o.render_visbuffer(cam, sun)
+        g.render(cam, sun)
+        plain.render(cam, sun)
+        assert covered(ovis).sum() > 5000
+        assert np.array_equal(g.read_visbuffer_u64(), ovis)
+        check_color(o, g)
+        assert np.array_equal(g.read_color(), plain.read_color())
+    g.close()
+    plain.close()
+
+
 def test_known_answer_triangle():
     W = H = 64
     sc = fb_triangle_scene([[(8, 8, 5.0), (8, 40, 5.0), (40, 8, 5.0)]], W, H)
