@@ -47,6 +47,8 @@ pub const RDR_FORMAT_BC1: u32 = 3;
 pub const RDR_FORMAT_BC2: u32 = 4;
 pub const RDR_FORMAT_BC3: u32 = 5;
 pub const RDR_FORMAT_BC4: u32 = 6;
+pub const RDR_FORMAT_BC7: u32 = 7;
+pub const RDR_FORMAT_BC7_SRGB: u32 = 8;
 pub const RDR_NO_TEXTURE: u32 = 0xFFFF_FFFF;
 pub const RDR_VIS_CLEAR: u64 = 0x7FFF_FFFF_FFFF_FFFF;
 

@@ -152,13 +152,16 @@ typedef struct rdr_ubo {
 #define RDR_FORMAT_RGBA8_SRGB 1u
 #define RDR_FORMAT_RGBA32F 2u
 /* Block-compressed 2D images, as a .dds file stores them (image_loader.rs:63-135 hands the blocks
- * to Vulkan; the sRGB variants of BC1-BC3 are bound as UNORM there, :72-74, so there is one
- * code per block layout).  Decoded to RGBA8_UNORM on the GPU when the scene is uploaded.
+ * to Vulkan; the sRGB variants of BC1-BC3 are bound as UNORM there, :72-74, so those have one
+ * code per block layout, while BC7 keeps its sRGB variant, :81-82).  Decoded to RGBA8 on the GPU
+ * when the scene is uploaded: RGBA8_SRGB for RDR_FORMAT_BC7_SRGB, RGBA8_UNORM for the others.
  * Level i holds ceil(w_i / 4) x ceil(h_i / 4) blocks of 8 (BC1, BC4) or 16 bytes, row-major. */
 #define RDR_FORMAT_BC1 3u /* RGB565 end points, 1-bit punch-through alpha */
 #define RDR_FORMAT_BC2 4u /* explicit 4-bit alpha + BC1 colours */
 #define RDR_FORMAT_BC3 5u /* interpolated alpha + BC1 colours */
 #define RDR_FORMAT_BC4 6u /* one interpolated channel (red), unorm */
+#define RDR_FORMAT_BC7 7u /* eight block modes, up to three end-point pairs, RGBA */
+#define RDR_FORMAT_BC7_SRGB 8u /* the same blocks; red, green and blue hold sRGB-encoded values */
 
 /* 2D image: mip levels tightly packed, level 0 first, rows top to bottom;
  * level i is max(1,width>>i) x max(1,height>>i). */
@@ -169,7 +172,7 @@ typedef struct rdr_image_desc {
     uint32_t format;
 } rdr_image_desc;
 
-/* Decode a block-compressed mip chain (RDR_FORMAT_BC1..BC4) to tightly packed RGBA8 levels, host
+/* Decode a block-compressed mip chain (RDR_FORMAT_BC1..BC7_SRGB) to tightly packed RGBA8 levels, host
  * memory to host memory, with the kernel rdr_set_scene uses at upload.  What the sampler hardware
  * does per fetch behind vkCmdCopyBufferToImage of a BC image (image_loader.rs:96-121). */
 int rdr_decode_bc(int device, uint32_t format, uint32_t width, uint32_t height, uint32_t mip_count, const void* blocks,
@@ -180,7 +183,7 @@ int rdr_decode_bc(int device, uint32_t format, uint32_t width, uint32_t height, 
  * and bit-identical output; the two staging buffers rdr_decode_bc allocates per call are replaced by
  * a fixed array inside the library's code object (7.5 MiB per GPU, held until the process ends), and
  * the call makes no hipMalloc / hipFree.  Limit: the chain's blocks must fit 1.5 MiB and its decoded
- * levels (each padded to 16 bytes) 6 MiB, i.e. up to a full 1024 x 1024 mip chain in any of the four
+ * levels (each padded to 16 bytes) 6 MiB, i.e. up to a full 1024 x 1024 mip chain in any of the block
  * formats; a larger chain is refused with an error and nothing is written.  All calls on one GPU
  * share the array: calls that overlap on one GPU race, the caller serialises them. */
 int rdr_decode_bc_noalloc(int device, uint32_t format, uint32_t width, uint32_t height, uint32_t mip_count,

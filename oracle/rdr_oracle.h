@@ -34,7 +34,7 @@ int orc_shade(const rdr_scene_desc* scene, const rdr_ubo* ubo, const uint64_t* v
               const uint8_t* draw_lod, uint32_t row_lo, uint32_t row_hi, uint8_t* out_rgba8,
               float* out_linear);
 
-/* Block-compressed mip chain (RDR_FORMAT_BC1..BC4) -> tightly packed RGBA8 levels. */
+/* Block-compressed mip chain (RDR_FORMAT_BC1..BC7_SRGB) -> tightly packed RGBA8 levels. */
 int orc_decode_bc(uint32_t format, uint32_t width, uint32_t height, uint32_t mip_count, const void* blocks, void* out_rgba8);
 
 /* Skybox pass: fills the pixels of rows [row_lo, row_hi) whose key is the clear

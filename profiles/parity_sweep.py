@@ -112,7 +112,7 @@ if os.environ.get("SWEEP_PART", "all") in ("all", "bc"):
     bad = 0
     for seed in range(400, 600):
         rng = np.random.default_rng(seed)
-        fmt = int(rng.integers(3, 7))  # RDR_FORMAT_BC1 .. BC4
+        fmt = int(rng.integers(3, 9))  # RDR_FORMAT_BC1 .. BC7_SRGB
         w, h = int(rng.integers(1, 300)), int(rng.integers(1, 300))
         mips = int(rng.integers(1, int(np.log2(max(w, h))) + 2))
         img = BlockImage(np.zeros(0, np.uint8), w, h, mips, fmt)

@@ -78,6 +78,7 @@ FORMAT_RGBA8_UNORM, FORMAT_RGBA8_SRGB, FORMAT_RGBA32F = 0, 1, 2
 (FRAME_DEFERRED_OVERFLOW, FRAME_SETUP_OVERFLOW, FRAME_BIN_OVERFLOW, FRAME_MID_OVERFLOW, FRAME_FRAG_OVERFLOW,
  FRAME_LIST_OVERFLOW, FRAME_SHADOW_STACK, FRAME_PEER_TIMEOUT) = 1, 2, 4, 8, 16, 32, 64, 128
 FORMAT_BC1, FORMAT_BC2, FORMAT_BC3, FORMAT_BC4 = 3, 4, 5, 6  # block-compressed, decoded to RGBA8_UNORM at upload
+FORMAT_BC7, FORMAT_BC7_SRGB = 7, 8  # decoded to RGBA8_UNORM / RGBA8_SRGB at upload
 VIS_CLEAR = 0x7FFFFFFFFFFFFFFF
 
 

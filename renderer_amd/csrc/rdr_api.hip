@@ -271,7 +271,7 @@ int validate_scene(const rdr_scene_desc& s) {
         if (!im.data) continue;
         RDR_CHECK(im.width && im.height && im.mip_count >= 1 && im.mip_count <= 17, "scene: image dimensions / mip count invalid");
         RDR_CHECK(im.width <= 32768 && im.height <= 32768, "scene: image larger than 32768 x 32768 (the sampler indexes a level's texels with 31 bits)");
-        RDR_CHECK(im.format <= RDR_FORMAT_BC4, "scene: unknown image format");
+        RDR_CHECK(im.format <= RDR_FORMAT_BC7_SRGB, "scene: unknown image format");
     }
     return 0;
 }
@@ -298,7 +298,7 @@ GpuImage pack_image(TexelPacker& tp, const rdr_image_desc& im) {
     if (!im.data) return g; // mip_count 0: samples as zero
     const bool blocks = im.format >= RDR_FORMAT_BC1;
     g.width = im.width; g.height = im.height; g.mip_count = im.mip_count;
-    g.format = blocks ? RDR_FORMAT_RGBA8_UNORM : im.format;
+    g.format = blocks ? (im.format == RDR_FORMAT_BC7_SRGB ? RDR_FORMAT_RGBA8_SRGB : RDR_FORMAT_RGBA8_UNORM) : im.format;
     size_t bytes = 0;
     for (uint32_t l = 0; l < im.mip_count; ++l) {
         g.level_offset[l] = (uint32_t)bytes;

@@ -1,17 +1,21 @@
-// rdr_bc.hip — block-compressed textures (BC1, BC2, BC3, BC4 unorm) expanded to RGBA8 on the GPU
-// when a scene is uploaded.
+// rdr_bc.hip — block-compressed textures (BC1, BC2, BC3, BC4 unorm, BC7) expanded to RGBA8 on the
+// GPU when a scene is uploaded.
 //
 // The reference hands the blocks of a .dds file to Vulkan unchanged
 // (renderer/src/renderer/image_loader.rs:63-135) and the sampler hardware decodes them; here the
 // sampler is software over RGBA8 texels, so the blocks are decoded once, at upload, and filtering
 // then sees exactly the texel values a block decoder produces.  The interpolated palette entries
 // follow the usual integer forms, rounded to nearest: (2a + b + 1) / 3 for colours, and
-// ((7 - i)a + ib + 3) / 7 or ((5 - i)a + ib + 2) / 5 for the single-channel ramp.
+// ((7 - i)a + ib + 3) / 7 or ((5 - i)a + ib + 2) / 5 for the single-channel ramp.  BC7 is specified
+// bit-exactly: ((64 - w)a + wb + 32) >> 6 with the format's weight tables.
 #include <hip/hip_runtime.h>
 
 #include <mutex>
 
 #include "rdr_internal.h"
+
+#define BC7_TABLE static __device__ const
+#include "rdr_bc7_tables.h"
 
 // Staging memory of rdr_decode_bc_noalloc: the blocks of a mip chain in the first part, the decoded
 // texels in the second.  It lives in the code object, so every GPU the library runs on holds its
@@ -92,6 +96,116 @@ __device__ inline void ramp_block(const uint8_t* b, uint32_t* v) {
     for (int i = 0; i < 16; ++i) v[i] = pal[(sel >> (3 * i)) & 7u];
 }
 
+// ---- BC7 ----
+// Per mode: subsets, partition bits, rotation bits, index-selector bit, colour bits, alpha bits,
+// one p bit per end point, one p bit per subset, bits of the first and of the second index set.
+struct Bc7Mode {
+    uint8_t subsets, partition_bits, rotation_bits, selector_bit, color_bits, alpha_bits, endpoint_p, shared_p, index_bits, index2_bits;
+};
+__device__ const Bc7Mode kBc7Modes[8] = {
+    {3, 4, 0, 0, 4, 0, 1, 0, 3, 0}, {2, 6, 0, 0, 6, 0, 0, 1, 3, 0}, {3, 6, 0, 0, 5, 0, 0, 0, 2, 0}, {2, 6, 0, 0, 7, 0, 1, 0, 2, 0},
+    {1, 0, 2, 1, 5, 6, 0, 0, 2, 3}, {1, 0, 2, 0, 7, 8, 0, 0, 2, 2}, {1, 0, 0, 0, 7, 7, 1, 0, 4, 0}, {2, 6, 0, 0, 5, 5, 1, 0, 2, 0},
+};
+// interpolation weights of 2-, 3- and 4-bit indices, at offsets 0, 4 and 12
+__device__ const uint8_t kBc7Weights[28] = {0, 21, 43, 64, 0, 9, 18, 27, 37, 46, 55, 64, 0, 4, 9, 13, 17, 21, 26, 30, 34, 38, 43, 47, 51, 55, 60, 64};
+
+// The 128 bits of a block as two words; `at` advances over the fields, lowest bit first.
+struct Bc7Bits {
+    unsigned long long lo, hi;
+    uint32_t at;
+    __device__ uint32_t take(uint32_t count) { // count <= 8
+        unsigned long long v;
+        if (at >= 64u) v = hi >> (at - 64u);
+        else v = at ? (lo >> at) | (hi << (64u - at)) : lo;
+        at += count;
+        return (uint32_t)v & ((1u << count) - 1u);
+    }
+};
+
+// Widens a `bits`-wide end-point value to eight bits by repeating its top bits below it.
+__device__ inline uint32_t bc7_widen(uint32_t v, uint32_t bits) {
+    v <<= 8u - bits;
+    return v | (v >> bits);
+}
+
+__device__ inline uint32_t bc7_mix(uint32_t a, uint32_t b, uint32_t w) { return ((64u - w) * a + w * b + 32u) >> 6; }
+
+// One BC7 block -> sixteen RGBA8 texels, row-major.
+__device__ void bc7_block(const uint8_t* b, uint32_t* px) {
+    Bc7Bits in{0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        in.lo |= (unsigned long long)b[i] << (8 * i);
+        in.hi |= (unsigned long long)b[8 + i] << (8 * i);
+    }
+    const uint32_t low = (uint32_t)in.lo & 255u;
+    if (low == 0u) { // the reserved mode: all zero
+#pragma unroll
+        for (int t = 0; t < 16; ++t) px[t] = 0u;
+        return;
+    }
+    const uint32_t mode = (uint32_t)__ffs((int)low) - 1u;
+    const Bc7Mode m = kBc7Modes[mode];
+    in.at = mode + 1u;
+    const uint32_t partition = in.take(m.partition_bits);
+    const uint32_t rotation = in.take(m.rotation_bits);
+    const uint32_t selector = in.take(m.selector_bit);
+    const uint32_t ends = 2u * m.subsets;
+    uint32_t e[6][4];
+    for (uint32_t ch = 0; ch < 3u; ++ch)
+        for (uint32_t k = 0; k < ends; ++k) e[k][ch] = in.take(m.color_bits);
+    for (uint32_t k = 0; k < ends; ++k) e[k][3] = in.take(m.alpha_bits);
+    const uint32_t extra = m.endpoint_p | m.shared_p;
+    if (extra) {
+        uint32_t p = 0;
+        for (uint32_t k = 0; k < ends; ++k) {
+            if (m.endpoint_p || !(k & 1u)) p = in.take(1u);
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) e[k][ch] = (e[k][ch] << 1) | p;
+        }
+    }
+    const uint32_t cbits = m.color_bits + extra, abits = m.alpha_bits ? m.alpha_bits + extra : 0u;
+    for (uint32_t k = 0; k < ends; ++k) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) e[k][ch] = bc7_widen(e[k][ch], cbits);
+        e[k][3] = abits ? bc7_widen(e[k][3], abits) : 255u;
+    }
+    uint32_t shape = 0u, anchor1 = 16u, anchor2 = 16u; // 16: no such anchor
+    if (m.subsets == 2) {
+        shape = kBc7Shape2[partition];
+        anchor1 = kBc7Anchor2[partition];
+    } else if (m.subsets == 3) {
+        shape = kBc7Shape3[partition];
+        anchor1 = kBc7Anchor3a[partition];
+        anchor2 = kBc7Anchor3b[partition];
+    }
+    // the second index set follows the first, whose length is 16 indices less one bit per subset
+    Bc7Bits in2 = in;
+    in2.at = in.at + 16u * m.index_bits - m.subsets;
+    const uint32_t table1 = m.index_bits == 2 ? 0u : (m.index_bits == 3 ? 4u : 12u);
+    const uint32_t table2 = m.index2_bits == 2 ? 0u : 4u;
+    for (uint32_t t = 0; t < 16u; ++t) {
+        const uint32_t subset = (shape >> (2u * t)) & 3u;
+        const bool is_anchor = t == 0u || t == anchor1 || t == anchor2;
+        uint32_t wc = kBc7Weights[table1 + in.take(m.index_bits - (is_anchor ? 1u : 0u))], wa = wc;
+        if (m.index2_bits) {
+            const uint32_t w2 = kBc7Weights[table2 + in2.take(m.index2_bits - (t == 0u ? 1u : 0u))];
+            if (selector) wc = w2;
+            else wa = w2;
+        }
+        const uint32_t* e0 = e[2u * subset];
+        const uint32_t* e1 = e[2u * subset + 1u];
+        uint32_t c[4];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) c[ch] = bc7_mix(e0[ch], e1[ch], wc);
+        c[3] = bc7_mix(e0[3], e1[3], wa);
+        if (rotation == 1u) { const uint32_t s = c[3]; c[3] = c[0]; c[0] = s; }
+        else if (rotation == 2u) { const uint32_t s = c[3]; c[3] = c[1]; c[1] = s; }
+        else if (rotation == 3u) { const uint32_t s = c[3]; c[3] = c[2]; c[2] = s; }
+        px[t] = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
+    }
+}
+
 // One thread per 4x4 block; texels outside the level (levels smaller than a block) are dropped.
 __global__ __launch_bounds__(256) void k_decode_bc(uint32_t format, uint32_t width, uint32_t height, const uint8_t* blocks, uint32_t* out) {
     const uint32_t nbx = (width + 3u) / 4u, nby = (height + 3u) / 4u;
@@ -101,7 +215,9 @@ __global__ __launch_bounds__(256) void k_decode_bc(uint32_t format, uint32_t wid
     const uint32_t block_bytes = (format == RDR_FORMAT_BC1 || format == RDR_FORMAT_BC4) ? 8u : 16u;
     const uint8_t* b = blocks + (size_t)bi * block_bytes;
     uint32_t px[16];
-    if (format == RDR_FORMAT_BC1) {
+    if (format >= RDR_FORMAT_BC7) {
+        bc7_block(b, px);
+    } else if (format == RDR_FORMAT_BC1) {
         color_block(b, true, px);
     } else if (format == RDR_FORMAT_BC2) {
         color_block(b + 8, false, px);
@@ -145,7 +261,7 @@ size_t rdr_bc_level_bytes(uint32_t format, uint32_t width, uint32_t height) {
 // Decodes one level: `blocks` and `out` are device pointers, `out` width * height RGBA8 texels,
 // 16-byte aligned when the width is a multiple of four.
 int rdr_launch_decode_bc(uint32_t format, uint32_t width, uint32_t height, const uint8_t* blocks, uint32_t* out, hipStream_t stream) {
-    RDR_CHECK(format >= RDR_FORMAT_BC1 && format <= RDR_FORMAT_BC4, "decode_bc: format is not a block-compressed one");
+    RDR_CHECK(format >= RDR_FORMAT_BC1 && format <= RDR_FORMAT_BC7_SRGB, "decode_bc: format is not a block-compressed one");
     RDR_CHECK(width && height, "decode_bc: empty level");
     const uint32_t n = ((width + 3u) / 4u) * ((height + 3u) / 4u);
     hipLaunchKernelGGL(k_decode_bc, dim3((n + 255u) / 256u), dim3(256), 0, stream, format, width, height, blocks, out);
@@ -177,7 +293,7 @@ int scratch_on_device(int device, uint8_t** out) {
 // two staging buffers replaced by the file-scope array above.  Calls no hipMalloc / hipFree.
 extern "C" int rdr_decode_bc_noalloc(int device, uint32_t format, uint32_t width, uint32_t height, uint32_t mip_count,
                                      const void* blocks, size_t block_bytes, void* out_rgba8) {
-    RDR_CHECK(format >= RDR_FORMAT_BC1 && format <= RDR_FORMAT_BC4, "decode_bc_noalloc: format must be RDR_FORMAT_BC1 .. RDR_FORMAT_BC4");
+    RDR_CHECK(format >= RDR_FORMAT_BC1 && format <= RDR_FORMAT_BC7_SRGB, "decode_bc_noalloc: format must be RDR_FORMAT_BC1 .. RDR_FORMAT_BC7_SRGB");
     RDR_CHECK(blocks && out_rgba8, "decode_bc_noalloc: null pointer");
     RDR_CHECK(width && height && mip_count >= 1 && mip_count <= 17, "decode_bc_noalloc: dimensions / mip count invalid");
     size_t need = 0, padded = 0;
@@ -218,7 +334,7 @@ extern "C" int rdr_decode_bc_noalloc(int device, uint32_t format, uint32_t width
 // the same kernel without the trip back.
 extern "C" int rdr_decode_bc(int device, uint32_t format, uint32_t width, uint32_t height, uint32_t mip_count, const void* blocks,
                              size_t block_bytes, void* out_rgba8) {
-    RDR_CHECK(format >= RDR_FORMAT_BC1 && format <= RDR_FORMAT_BC4, "decode_bc: format must be RDR_FORMAT_BC1 .. RDR_FORMAT_BC4");
+    RDR_CHECK(format >= RDR_FORMAT_BC1 && format <= RDR_FORMAT_BC7_SRGB, "decode_bc: format must be RDR_FORMAT_BC1 .. RDR_FORMAT_BC7_SRGB");
     RDR_CHECK(blocks && out_rgba8, "decode_bc: null pointer");
     RDR_CHECK(width && height && mip_count >= 1 && mip_count <= 17, "decode_bc: dimensions / mip count invalid");
     size_t need = 0, padded = 0;

@@ -4,10 +4,10 @@ the ddsfile crate and hands the blocks to Vulkan unchanged.
 
 Followed from the reference: the format comes from the DX10 header when there is one and from
 the legacy four-character code otherwise; the sRGB variants of BC1-BC3 are bound as UNORM
-(image_loader.rs:72-74); the level count is the header's mip-map count (1 when absent); levels
+(image_loader.rs:72-74) while BC7 keeps its sRGB variant (:81-82); the level count is the header's mip-map count (1 when absent); levels
 are ceil(w/4) x ceil(h/4) blocks, tightly packed, largest first (:96-121).
 
-Not supported here, with a clear error: BC7 and BC6H (no decoder in this library), BC4 / BC5
+Not supported here, with a clear error: BC6H (no decoder in this library), BC4 / BC5
 signed, and BC5, which the reference binds as a BC4 image while keeping BC5's 16-byte block stride
 (:77-78,88-91), i.e. it cannot render such a file correctly either.
 """
@@ -24,13 +24,13 @@ _DDPF_FOURCC = 0x4
 _DDSD_MIPMAPCOUNT = 0x20000
 # DXGI_FORMAT codes of the DX10 header
 _DXGI = {71: abi.FORMAT_BC1, 72: abi.FORMAT_BC1, 74: abi.FORMAT_BC2, 75: abi.FORMAT_BC2,
-         77: abi.FORMAT_BC3, 78: abi.FORMAT_BC3, 80: abi.FORMAT_BC4}
-_DXGI_UNSUPPORTED = {81: "BC4_SNORM", 83: "BC5_UNORM", 84: "BC5_SNORM", 95: "BC6H_UF16", 96: "BC6H_SF16",
-                     98: "BC7_UNORM", 99: "BC7_UNORM_SRGB"}
+         77: abi.FORMAT_BC3, 78: abi.FORMAT_BC3, 80: abi.FORMAT_BC4, 98: abi.FORMAT_BC7, 99: abi.FORMAT_BC7_SRGB}
+_DXGI_UNSUPPORTED = {81: "BC4_SNORM", 83: "BC5_UNORM", 84: "BC5_SNORM", 95: "BC6H_UF16", 96: "BC6H_SF16"}
 # legacy four-character codes and the DXGI format ddsfile derives from them
 _FOURCC = {b"DXT1": 71, b"DXT2": 74, b"DXT3": 74, b"DXT4": 77, b"DXT5": 77, b"ATI1": 80, b"BC4U": 80,
            b"BC4S": 81, b"ATI2": 83, b"BC5U": 83, b"BC5S": 84}
-_DXGI_OF_FORMAT = {abi.FORMAT_BC1: 71, abi.FORMAT_BC2: 74, abi.FORMAT_BC3: 77, abi.FORMAT_BC4: 80}
+_DXGI_OF_FORMAT = {abi.FORMAT_BC1: 71, abi.FORMAT_BC2: 74, abi.FORMAT_BC3: 77, abi.FORMAT_BC4: 80,
+                   abi.FORMAT_BC7: 98, abi.FORMAT_BC7_SRGB: 99}
 
 
 class DdsError(ValueError):
@@ -75,8 +75,10 @@ def read_dds(path):
 
 
 def write_dds(path, image, dx10=False):
-    """Writes a ``BlockImage`` (test fixtures and tools).  ``dx10``: with the extended header."""
+    """Writes a ``BlockImage`` (test fixtures and tools).  ``dx10``: with the extended header, which
+    BC7 always gets (it has no legacy code)."""
     legacy = {abi.FORMAT_BC1: b"DXT1", abi.FORMAT_BC2: b"DXT3", abi.FORMAT_BC3: b"DXT5", abi.FORMAT_BC4: b"ATI1"}
+    dx10 = dx10 or image.format not in legacy
     flags = 0x1 | 0x2 | 0x4 | 0x1000 | 0x80000 | (_DDSD_MIPMAPCOUNT if image.mip_count > 1 else 0)
     head = struct.pack("<7I", 124, flags, image.height, image.width, image.level_bytes(0), 0,
                        image.mip_count if image.mip_count > 1 else 0) + b"\0" * 44
@@ -106,4 +108,4 @@ def decode(image, device=0):
     for h, w in dims:
         mips.append(out[at:at + h * w * 4].reshape(h, w, 4).copy())
         at += h * w * 4
-    return Image(mips, srgb=False)
+    return Image(mips, srgb=image.format == abi.FORMAT_BC7_SRGB)

@@ -310,6 +310,9 @@ def _load_texture_images(doc, base_dir):
                 except (OSError, DdsError):
                     if ext == ".dds":
                         raise
+            if ext == ".ktx2":  # image_loader.rs:264
+                from .ktx2 import load_image_ktx2
+                cache[path] = load_image_ktx2(path)
             if cache[path] is None:
                 with PilImage.open(path) as im:
                     cache[path] = Image([np.array(im.convert("RGBA"), np.uint8)], srgb="basecolor" in path)

@@ -50,7 +50,7 @@ class Image:
 @dataclass
 class BlockImage:
     """Block-compressed texture as a .dds file holds it: ``data`` is the mip chain's blocks (uint8),
-    ``format`` one of ``abi.FORMAT_BC1`` .. ``FORMAT_BC4``.  The library expands it to RGBA8 on the
+    ``format`` one of ``abi.FORMAT_BC1`` .. ``FORMAT_BC7_SRGB``.  The library expands it to RGBA8 on the
     GPU when the scene is uploaded."""
     data: np.ndarray
     width: int

@@ -88,9 +88,7 @@ def _read_cube(f):
     if n == 0:
         return None
     if fmt >= abi.FORMAT_BC1:
-        img = BlockImage(np.zeros(0, np.uint8), w, h, mips, fmt)
-        img.data = np.frombuffer(f.read(sum(img.level_bytes(l) for l in range(mips))), np.uint8).copy()
-        return img
+        raise ValueError(f"cubemap format {fmt}: cubemaps hold RGBA8 or RGBA32F texels, not blocks")
     dt = _texel_dtype(fmt)
     out = []
     for l in range(mips):

@@ -3,7 +3,9 @@ renderer/src/renderer/image_loader.rs:63-135), the CPU decode of the oracle agai
 blocks, and the GPU decode (``rdr_decode_bc`` and the scene upload) against the oracle, bit for bit.
 
 Parity unpinned against the reference itself: it ships no compressed texture and no decoded image;
-the expected values below are worked out by hand from the block layouts."""
+the expected values below are worked out by hand from the block layouts.  BC7, which the format
+defines bit-exactly, is also held against the output of an independent decoder on 1488 blocks
+(tests/golden/bc7_blocks.npz, made by tests/golden/make_bc7_blocks.py)."""
 import ctypes as C
 import os
 import struct
@@ -15,7 +17,8 @@ from renderer_amd import abi
 from renderer_amd.dds import DdsError, read_dds, write_dds
 from renderer_amd.scene import BlockImage, Image
 
-BC = [abi.FORMAT_BC1, abi.FORMAT_BC2, abi.FORMAT_BC3, abi.FORMAT_BC4]
+BC = [abi.FORMAT_BC1, abi.FORMAT_BC2, abi.FORMAT_BC3, abi.FORMAT_BC4, abi.FORMAT_BC7, abi.FORMAT_BC7_SRGB]
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def oracle_decode(oracle, img):
@@ -97,6 +100,70 @@ def test_bc4_is_red_only(oracle):
     assert (px[..., 1] == 0).all() and (px[..., 2] == 0).all() and (px[..., 3] == 255).all()
 
 
+def bc7_golden():
+    d = np.load(os.path.join(GOLDEN, "bc7_blocks.npz"))
+    return d["blocks"], d["texels"]
+
+
+def blocks_in_a_row(texels_image, n):
+    """(4, 4n, 4) image of n blocks side by side -> (n, 16, 4), row-major inside each block."""
+    return texels_image.reshape(4, n, 4, 4).transpose(1, 0, 2, 3).reshape(n, 16, 4)
+
+
+def test_bc7_matches_an_independent_decoder_in_every_mode(oracle):
+    blocks, want = bc7_golden()
+    n = len(blocks)
+    modes = [(int(b) & -int(b)).bit_length() - 1 for b in blocks[:, 0]]
+    assert all(modes.count(m) >= 100 for m in range(8))
+    got = oracle_decode(oracle, BlockImage(blocks.reshape(-1), 4 * n, 4, 1, abi.FORMAT_BC7))[0]
+    assert np.array_equal(blocks_in_a_row(got, n), want)
+    srgb = oracle_decode(oracle, BlockImage(blocks.reshape(-1), 4 * n, 4, 1, abi.FORMAT_BC7_SRGB))[0]
+    assert np.array_equal(srgb, got)  # the sRGB code changes how the texels are read later, not the decode
+
+
+def bc7_fields(*fields):
+    """(value, bits) pairs, lowest bit first -> the 16 bytes of a block."""
+    v = at = 0
+    for value, bits in fields:
+        assert 0 <= value < (1 << bits)
+        v |= value << at
+        at += bits
+    assert at == 128
+    return v.to_bytes(16, "little")
+
+
+def test_bc7_mode_6_block_by_hand(oracle):
+    # mode 6: one subset, 7-bit RGBA end points with a p bit each, 4-bit indices (texel 0: 3 bits).
+    # end point 0 = (0, 0, 0, 127) p 0 -> (0, 0, 0, 254); end point 1 = (127, 127, 127, 127) p 1 -> 255 everywhere
+    weights = [0, 4, 9, 13, 17, 21, 26, 30, 34, 38, 43, 47, 51, 55, 60, 64]
+    order = [0] + [(5 * i) % 16 for i in range(1, 16)]  # texel 0's index must fit three bits
+    raw = bc7_fields((1 << 6, 7), (0, 7), (127, 7), (0, 7), (127, 7), (0, 7), (127, 7), (127, 7), (127, 7), (0, 1), (1, 1),
+                     (order[0], 3), *[(i, 4) for i in order[1:]])
+    px = oracle_decode(oracle, one_block(abi.FORMAT_BC7, raw))[0].reshape(16, 4)
+    for t, i in enumerate(order):
+        w = weights[i]
+        assert px[t].tolist() == [(w * 255 + 32) >> 6] * 3 + [((64 - w) * 254 + w * 255 + 32) >> 6], t
+
+
+def test_bc7_mode_5_rotation_swaps_alpha_with_a_colour_by_hand(oracle):
+    # mode 5: 7-bit colours, 8-bit alpha, no p bits, 2-bit colour indices then 2-bit alpha indices, 2 rotation bits
+    def block(rotation):
+        return bc7_fields((1 << 5, 6), (rotation, 2), (10, 7), (10, 7), (20, 7), (20, 7), (30, 7), (30, 7), (200, 8), (100, 8),
+                          (0, 1), *[(0, 2)] * 15, (1, 1), *[(3, 2)] * 15)
+    r, g, b = ((v << 1) | (v >> 6) for v in (10, 20, 30))
+    a0 = ((64 - 21) * 200 + 21 * 100 + 32) >> 6  # texel 0: alpha index 1, weight 21
+    a1 = (64 * 100 + 32) >> 6                    # the others: alpha index 3, weight 64
+    for rotation, want0 in ((0, [r, g, b, a0]), (1, [a0, g, b, r]), (2, [r, a0, b, g]), (3, [r, g, a0, b])):
+        px = oracle_decode(oracle, one_block(abi.FORMAT_BC7, block(rotation)))[0].reshape(16, 4)
+        assert px[0].tolist() == want0, rotation
+        assert px[5].tolist() == [a1 if c == rotation - 1 else want0[c] for c in range(3)] + [a1 if rotation == 0 else want0[3]]
+
+
+def test_bc7_reserved_mode_decodes_to_zero(oracle):
+    raw = bytes([0]) + bytes(range(1, 16))
+    assert not oracle_decode(oracle, one_block(abi.FORMAT_BC7, raw))[0].any()
+
+
 def test_partial_blocks_and_mip_chain_layout(oracle):
     img = random_image(abi.FORMAT_BC3, 10, 6, 4, 1)  # levels 10x6, 5x3, 2x1, 1x1: 3x2, 2x1, 1, 1 blocks
     assert [img.level_bytes(l) for l in range(4)] == [96, 32, 16, 16]
@@ -139,6 +206,16 @@ def test_dds_srgb_codes_are_bound_as_unorm_and_legacy_codes_map(tmp_path):
     assert read_dds(path).format == abi.FORMAT_BC3
 
 
+def test_dds_bc7_keeps_its_srgb_code_and_always_has_the_extended_header(tmp_path):
+    """image_loader.rs:81-82: BC7_UNorm and BC7_UNorm_sRGB stay two Vulkan formats."""
+    path = str(tmp_path / "t.dds")
+    for fmt, code in ((abi.FORMAT_BC7, 98), (abi.FORMAT_BC7_SRGB, 99)):
+        write_dds(path, random_image(fmt, 12, 8, 2, 3))
+        raw = open(path, "rb").read()
+        assert raw[84:88] == b"DX10" and struct.unpack_from("<I", raw, 128)[0] == code
+        assert read_dds(path).format == fmt
+
+
 def test_dds_errors(tmp_path):
     path = str(tmp_path / "t.dds")
     open(path, "wb").write(b"PNG " + b"\0" * 200)
@@ -146,7 +223,7 @@ def test_dds_errors(tmp_path):
         read_dds(path)
     write_dds(path, random_image(abi.FORMAT_BC1, 8, 8, 1, 2), dx10=True)
     raw = bytearray(open(path, "rb").read())
-    for code, name in ((98, "BC7_UNORM"), (83, "BC5_UNORM"), (95, "BC6H_UF16"), (81, "BC4_SNORM")):
+    for code, name in ((83, "BC5_UNORM"), (95, "BC6H_UF16"), (96, "BC6H_SF16"), (81, "BC4_SNORM")):
         struct.pack_into("<I", raw, 128, code)
         open(path, "wb").write(raw)
         with pytest.raises(DdsError, match=name):
@@ -214,6 +291,17 @@ def test_gpu_decode_matches_the_oracle(oracle, fmt, shape):
 
 
 @pytest.mark.gpu
+def test_gpu_bc7_matches_the_independent_decoder():
+    from renderer_amd import dds
+    blocks, want = bc7_golden()
+    n = len(blocks)
+    got = dds.decode(BlockImage(blocks.reshape(-1), 4 * n, 4, 1, abi.FORMAT_BC7)).mips[0]
+    assert np.array_equal(blocks_in_a_row(got, n), want)
+    reserved = bytes([0]) + bytes(range(1, 16))
+    assert not dds.decode(one_block(abi.FORMAT_BC7_SRGB, reserved)).mips[0].any()
+
+
+@pytest.mark.gpu
 def test_gpu_decode_rejects_bad_arguments():
     from renderer_amd import RendererError, dds
     img = random_image(abi.FORMAT_BC3, 16, 16, 2, 1)
@@ -225,7 +313,7 @@ def test_gpu_decode_rejects_bad_arguments():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fmt", [abi.FORMAT_BC1, abi.FORMAT_BC3])
+@pytest.mark.parametrize("fmt", [abi.FORMAT_BC1, abi.FORMAT_BC3, abi.FORMAT_BC7, abi.FORMAT_BC7_SRGB])
 def test_scene_with_block_texture_renders_like_its_decoded_twin(oracle, fmt):
     """An alpha-masked, textured quad whose albedo is block-compressed: the upload-time decode must
     give the frame the decoded RGBA8 image gives, key for key and byte for byte, and the oracle
@@ -247,7 +335,7 @@ def test_scene_with_block_texture_renders_like_its_decoded_twin(oracle, fmt):
     rng2 = np.random.default_rng(3)
     sc_blocks = scene(img)
     rng2 = np.random.default_rng(3)
-    sc_texels = scene(Image(oracle_decode(oracle, img), srgb=False))
+    sc_texels = scene(Image(oracle_decode(oracle, img), srgb=fmt == abi.FORMAT_BC7_SRGB))
     conf = RendererConfig(cull_enabled=False)
     out = []
     for sc in (sc_blocks, sc_texels):

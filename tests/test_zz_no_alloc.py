@@ -33,8 +33,9 @@ def _decode(fn, fmt, w, h, mips, blocks):
 def test_noalloc_decode_matches_allocating_decode():
     L = load_library()
     rng = np.random.default_rng(7)
-    # the second call is smaller than the first and the third smaller again, in another format
-    for fmt, w, h, mips in ((abi.FORMAT_BC3, 256, 128, 9), (abi.FORMAT_BC1, 52, 36, 3), (abi.FORMAT_BC4, 8, 8, 4)):
+    # every call is smaller than the one before it, and in another format
+    for fmt, w, h, mips in ((abi.FORMAT_BC3, 256, 128, 9), (abi.FORMAT_BC7, 96, 40, 4), (abi.FORMAT_BC1, 52, 36, 3),
+                            (abi.FORMAT_BC4, 8, 8, 4)):
         blocks = rng.integers(0, 256, _chain_bytes(fmt, w, h, mips), dtype=np.uint8)
         rc, want = _decode(L.rdr_decode_bc, fmt, w, h, mips, blocks)
         assert rc == 0, L.rdr_last_error().decode()
