@@ -36,6 +36,13 @@ static inline v3 v3_normalize(v3 a) {
     return v3_make(a.x / l, a.y / l, a.z / l);
 }
 
+/* normalize() of the shading pass's per-pixel vectors: reciprocal of the length, then three products (GLSL
+ * leaves the rounding of normalize() open; the GPU path does exactly this).  0 * inf -> NaN is kept. */
+static inline v3 v3_normalize_rcp(v3 a) {
+    float r = 1.0f / v3_len(a);
+    return v3_make(a.x * r, a.y * r, a.z * r);
+}
+
 /* Column-major 4x4 times column vector: ((c0*x + c1*y) + c2*z) + c3*w per row. */
 static inline v4 m4_mul_v4(const float* m, v4 v) {
     v4 r;

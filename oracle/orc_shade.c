@@ -416,7 +416,7 @@ static v4 brdf_lut_tap(const env_ctx* e, float x, float y) {
 }
 
 static v3 ibl_ggx(const env_ctx* e, v3 n, v3 v, float ndv, float rough, v3 refl0, float spec_w) {
-    v3 r = v3_normalize(reflect_neg(v, n));
+    v3 r = v3_normalize_rcp(reflect_neg(v, n));
     float mips = (float)e->ggx.mip_count;
     float lod = rough * (mips - 1.0f);
     v4 brdf = brdf_lut_tap(e, ndv, rough);
@@ -447,7 +447,7 @@ static v3 ibl_lambertian(const env_ctx* e, float ndv, v3 n, float rough, v3 diff
 static v3 ibl_charlie(const env_ctx* e, v3 n, v3 v, float ndv, float sr, v3 sc) {
     float mips = (float)e->charlie.mip_count;
     float lod = sr * (mips - 1.0f);
-    v3 r = v3_normalize(reflect_neg(v, n));
+    v3 r = v3_normalize_rcp(reflect_neg(v, n));
     float brdf = brdf_lut_tap(e, ndv, sr).z;
     v4 smp = orc_cube_sample_lod(&e->charlie, r, lod);
     return v3_scale(v3_mul(v3_make(smp.x, smp.y, smp.z), sc), brdf);
@@ -577,10 +577,10 @@ static v3 shade_pixel(const rdr_scene_desc* s, const rdr_ubo* u, const env_ctx* 
     v3 spec_color_factor = v3_make(mat.specular_factor[0] * sc4.x, mat.specular_factor[1] * sc4.y, mat.specular_factor[2] * sc4.z);
     float spec_factor_w = mat.specular_factor[3] * sp4.x;
 
-    v3 nnormal = v3_normalize(norm);
-    v3 ntangent = v3_normalize(tangent);
+    v3 nnormal = v3_normalize_rcp(norm);
+    v3 ntangent = v3_normalize_rcp(tangent);
     v3 bitangent = v3_scale(v3_cross(nnormal, ntangent), (v1->t[3] * v2->t[3]) * v3p->t[3]);
-    v3 nrm = v3_normalize(v3_add(v3_add(v3_scale(ntangent, nmap.x), v3_scale(bitangent, nmap.y)), v3_scale(nnormal, nmap.z)));
+    v3 nrm = v3_normalize_rcp(v3_add(v3_add(v3_scale(ntangent, nmap.x), v3_scale(bitangent, nmap.y)), v3_scale(nnormal, nmap.z)));
 
     v3 L = v3_normalize(v3_make(u->sun_direction[0], u->sun_direction[1], u->sun_direction[2]));
     int shadow_hit = shadow_any_hit(ss, w_pos, L, 1e-2f, 1000.0f);
@@ -614,8 +614,8 @@ static v3 shade_pixel(const rdr_scene_desc* s, const rdr_ubo* u, const env_ctx* 
     v3 r0 = specular, r90 = v3_splat(refl90);
 
     v3 cam = v3_make(u->camera_position[0], u->camera_position[1], u->camera_position[2]);
-    v3 v = v3_scale(v3_normalize(v3_sub(w_pos, cam)), -1.0f);
-    v3 h = v3_normalize(v3_add(L, v));
+    v3 v = v3_scale(v3_normalize_rcp(v3_sub(w_pos, cam)), -1.0f);
+    v3 h = v3_normalize_rcp(v3_add(L, v));
     float ndv = clampf(fabsf(v3_dot(nrm, v)), 0.001f, 1.0f);
     float ndl = clampf(v3_dot(nrm, L), 0.001f, 1.0f);
     float ndh = clampf(v3_dot(nrm, h), 0.0f, 1.0f);
@@ -637,7 +637,7 @@ static v3 shade_pixel(const rdr_scene_desc* s, const rdr_ubo* u, const env_ctx* 
     if (mat.material_type & RDR_MAT_CLEARCOAT) {
         v4 cn4 = sample_or_default(s, mat.clearcoat_texture, uv_id, nmap_def);
         v3 cm = v3_make(cn4.x * 2.0f - 1.0f, cn4.y * 2.0f - 1.0f, cn4.z * 2.0f - 1.0f);
-        v3 cnrm = v3_normalize(v3_add(v3_add(v3_scale(ntangent, cm.x), v3_scale(bitangent, cm.y)), v3_scale(nnormal, cm.z)));
+        v3 cnrm = v3_normalize_rcp(v3_add(v3_add(v3_scale(ntangent, cm.x), v3_scale(bitangent, cm.y)), v3_scale(nnormal, cm.z)));
         float cndv = clampf(fabsf(v3_dot(cnrm, v)), 0.001f, 1.0f);
         float cr = mat.clearcoat_factor[1];
         v3 cf0 = v3_splat(fi * fi);
@@ -688,8 +688,9 @@ int orc_shade(const rdr_scene_desc* s, const rdr_ubo* u, const uint64_t* vis, co
             const rdr_mesh_draw* d = &s->mesh_draws[lo];
             const rdr_mesh_lod* Ld = &s->meshes[d->mesh_index].lods[draw_lod[lo]];
             uint32_t meshlet = Ld->meshlet_offset + (instance - d->meshlet_visibility_offset);
-            float uvx = ((float)ix + 0.5f) / (float)W;
-            float uvy = 1.0f - ((float)iy + 0.5f) / (float)H;
+            /* the full-screen triangle's interpolated uv at the pixel centre: a product with 1 / W, 1 / H */
+            float uvx = ((float)ix + 0.5f) * (1.0f / (float)W);
+            float uvy = 1.0f - ((float)iy + 0.5f) * (1.0f / (float)H);
             v3 c = shade_pixel(s, u, &env, &ss, lo, meshlet, tri, uvx, uvy);
             o8[0] = srgb_encode(c.x); o8[1] = srgb_encode(c.y); o8[2] = srgb_encode(c.z); o8[3] = 255;
             if (of) { of[0] = c.x; of[1] = c.y; of[2] = c.z; of[3] = 1.0f; }

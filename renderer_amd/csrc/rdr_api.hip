@@ -423,6 +423,8 @@ FrameView make_frame_view(rdr_renderer* r) {
         fv.sun_unit[0] = x / l; fv.sun_unit[1] = y / l; fv.sun_unit[2] = z / l;
         fv.two_over_width = 2.0f / fv.ubo.screen_width;
         fv.two_over_height = 2.0f / fv.ubo.screen_height;
+        fv.inv_width = 1.0f / (float)fv.width;
+        fv.inv_height = 1.0f / (float)fv.height;
     }
     fv.sun_candidates = r->sun_candidates;
     fv.host_status = r->status_dev;

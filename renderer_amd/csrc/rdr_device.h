@@ -37,6 +37,14 @@ RDR_DEV vec3 normalize3(vec3 a) {
     float l = len3(a);
     return mk3(a.x / l, a.y / l, a.z / l);
 }
+// normalize() of the per-pixel shading vectors: one correctly rounded reciprocal of the length and three
+// products.  GLSL leaves normalize()'s rounding to the implementation (drivers lower it to
+// x * inversesqrt(dot(x, x))), and two of three divisions are a tenth of the shading pass's arithmetic.
+// A zero vector still gives NaN (0 * inf).
+RDR_DEV vec3 normalize3_rcp(vec3 a) {
+    const float r = 1.0f / len3(a);
+    return mk3(a.x * r, a.y * r, a.z * r);
+}
 RDR_DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 RDR_DEV float max3f(float a, float b, float c) { return fmaxf(a, fmaxf(b, c)); }
 

@@ -399,9 +399,11 @@ struct FrameView {
     uint32_t convex_skip; // 1: shadow rays that leave a closed convex mesh skip that mesh (0 only as a measurement hook)
     uint32_t sun_candidates; // 1: SceneView::sun_cand_* hold this frame's sun direction and transforms (0 only as a measurement hook)
     // Per-frame values that are the same in every lane, worked out once on the host with the arithmetic the kernels
-    // would use (same expressions, same rounding): the normalised sun direction and 2 / width, 2 / height.
+    // would use (same expressions, same rounding): the normalised sun direction, 2 / width, 2 / height, and the
+    // reciprocals 1 / width, 1 / height that turn a pixel centre into its 0..1 screen coordinate with a product.
     float sun_unit[3];
     float two_over_width, two_over_height;
+    float inv_width, inv_height;
     uint32_t shadow_defer; // 1: walks through a ray's own closed convex instance are left to k_shadow_walk (0 only as a measurement hook)
     // Per-workgroup statistics: every workgroup stores its partial counts in its own
     // slot with plain stores (no contended atomics); the host sums the slots on request.

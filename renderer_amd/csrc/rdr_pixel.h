@@ -106,8 +106,9 @@ RDR_DEV ListedPixel listed_pixel(const SceneView& sv, const FrameView& fv, uint3
     p.lod = df.material_lod >> 16;
     const uint32_t packed = p.pi, iy = packed >> 16, ix = packed & 0xFFFFu;
     p.pi = iy * fv.width + ix;
-    p.uvx = ((float)ix + 0.5f) / (float)fv.width;
-    p.uvy = 1.0f - ((float)iy + 0.5f) / (float)fv.height;
+    // the full-screen triangle's interpolated uv at the pixel centre (fullscreen_triangle.vert.glsl:7-9)
+    p.uvx = ((float)ix + 0.5f) * fv.inv_width;
+    p.uvy = 1.0f - ((float)iy + 0.5f) * fv.inv_height;
     return p;
 }
 

@@ -80,7 +80,7 @@ RDR_DEV vec4 brdf_lut_tap(const SceneView& sv, float x, float y) {
 }
 
 RDR_DEV vec3 ibl_ggx(const SceneView& sv, vec3 n, vec3 v, float ndv, float rough, vec3 refl0, float spec_w, vec4 brdf) {
-    const vec3 r = normalize3(reflect_neg(v, n));
+    const vec3 r = normalize3_rcp(reflect_neg(v, n));
     const float mips = (float)sv.ggx.mip_count;
     const float lod = rough * (mips - 1.0f);
     const vec4 sl = cube_sample_lod(sv.ggx, sv.texels, r, lod);
@@ -109,7 +109,7 @@ RDR_DEV vec3 ibl_lambertian(const SceneView& sv, float ndv, vec3 n, float rough,
 RDR_DEV vec3 ibl_charlie(const SceneView& sv, vec3 n, vec3 v, float ndv, float sr, vec3 sc) {
     const float mips = (float)sv.charlie.mip_count;
     const float lod = sr * (mips - 1.0f);
-    const vec3 r = normalize3(reflect_neg(v, n));
+    const vec3 r = normalize3_rcp(reflect_neg(v, n));
     const float brdf = brdf_lut_tap(sv, ndv, sr).z;
     const vec4 smp = cube_sample_lod(sv.charlie, sv.texels, r, lod);
     return (mk3(smp.x, smp.y, smp.z) * sc) * brdf;
@@ -208,10 +208,10 @@ RDR_DEV vec3 shade_pixel(const SceneView& sv, const float* srgb, const FrameView
     const vec3 spec_color_factor = mk3(mat.specular_factor[0] * sc4.x, mat.specular_factor[1] * sc4.y, mat.specular_factor[2] * sc4.z);
     const float spec_factor_w = mat.specular_factor[3] * sp4.x;
 
-    const vec3 nnormal = normalize3(norm);
-    const vec3 ntangent = normalize3(tangent);
+    const vec3 nnormal = normalize3_rcp(norm);
+    const vec3 ntangent = normalize3_rcp(tangent);
     const vec3 bitangent = cross3(nnormal, ntangent) * ((v1->t[3] * v2->t[3]) * v3->t[3]);
-    const vec3 nrm = normalize3((ntangent * nmap.x + bitangent * nmap.y) + nnormal * nmap.z);
+    const vec3 nrm = normalize3_rcp((ntangent * nmap.x + bitangent * nmap.y) + nnormal * nmap.z);
 
     const vec3 L = mk3(fv.sun_unit[0], fv.sun_unit[1], fv.sun_unit[2]);
 
@@ -244,8 +244,8 @@ RDR_DEV vec3 shade_pixel(const SceneView& sv, const float* srgb, const FrameView
     const vec3 r0 = specular, r90 = splat(refl90);
 
     const vec3 cam = mk3(u.camera_position[0], u.camera_position[1], u.camera_position[2]);
-    const vec3 v = normalize3(w_pos - cam) * -1.0f;
-    const vec3 h = normalize3(L + v);
+    const vec3 v = normalize3_rcp(w_pos - cam) * -1.0f;
+    const vec3 h = normalize3_rcp(L + v);
     const float ndv = clampf(fabsf(dot3(nrm, v)), 0.001f, 1.0f);
     const float ndl = clampf(dot3(nrm, L), 0.001f, 1.0f);
     const float ndh = clampf(dot3(nrm, h), 0.0f, 1.0f);
@@ -268,7 +268,7 @@ RDR_DEV vec3 shade_pixel(const SceneView& sv, const float* srgb, const FrameView
     if (mat.material_type & RDR_MAT_CLEARCOAT) {
         const vec4 cn4 = sample_or_default(sv, srgb, mat.clearcoat_texture, uv_id, nmap_def);
         const vec3 cm = mk3(cn4.x * 2.0f - 1.0f, cn4.y * 2.0f - 1.0f, cn4.z * 2.0f - 1.0f);
-        const vec3 cnrm = normalize3((ntangent * cm.x + bitangent * cm.y) + nnormal * cm.z);
+        const vec3 cnrm = normalize3_rcp((ntangent * cm.x + bitangent * cm.y) + nnormal * cm.z);
         const float cndv = clampf(fabsf(dot3(cnrm, v)), 0.001f, 1.0f);
         const float cr = mat.clearcoat_factor[1];
         const vec3 cf0 = splat(fi * fi);
