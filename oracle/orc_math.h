@@ -36,6 +36,23 @@ static inline v3 v3_normalize(v3 a) {
     return v3_make(a.x / l, a.y / l, a.z / l);
 }
 
+/* The shading pass's dot product and matrix products, with fused multiply-adds (fmaf is exact: one rounding per
+ * term).  GLSL leaves contraction open; the GPU path evaluates exactly these expressions.  The geometry stage
+ * keeps the unfused forms below, which the visibility keys are defined with. */
+static inline float v3_dot_fma(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+static inline v4 m4_mul_v4_fma(const float* m, v4 v) {
+    v4 r;
+    r.x = fmaf(m[12], v.w, fmaf(m[8], v.z, fmaf(m[4], v.y, m[0] * v.x)));
+    r.y = fmaf(m[13], v.w, fmaf(m[9], v.z, fmaf(m[5], v.y, m[1] * v.x)));
+    r.z = fmaf(m[14], v.w, fmaf(m[10], v.z, fmaf(m[6], v.y, m[2] * v.x)));
+    r.w = fmaf(m[15], v.w, fmaf(m[11], v.z, fmaf(m[7], v.y, m[3] * v.x)));
+    return r;
+}
+static inline v3 m4_mul_dir_fma(const float* m, v3 v) {
+    return v3_make(fmaf(m[8], v.z, fmaf(m[4], v.y, m[0] * v.x)), fmaf(m[9], v.z, fmaf(m[5], v.y, m[1] * v.x)),
+                   fmaf(m[10], v.z, fmaf(m[6], v.y, m[2] * v.x)));
+}
+
 /* normalize() of the shading pass's per-pixel vectors: reciprocal of the length, then three products (GLSL
  * leaves the rounding of normalize() open; the GPU path does exactly this).  0 * inf -> NaN is kept. */
 static inline v3 v3_normalize_rcp(v3 a) {

@@ -344,7 +344,7 @@ static bary_deriv calc_full_bary(v4 pt0, v4 pt1, v4 pt2, float ndcx, float ndcy,
 typedef struct { float v, dx, dy; } interp1;
 static interp1 interp_scalar(const bary_deriv* b, float a0, float a1, float a2) {
     v3 m = v3_make(a0, a1, a2);
-    interp1 r = {v3_dot(m, b->lambda), v3_dot(m, b->ddx), v3_dot(m, b->ddy)};
+    interp1 r = {v3_dot_fma(m, b->lambda), v3_dot_fma(m, b->ddx), v3_dot_fma(m, b->ddy)};
     return r;
 }
 static v3 interp_v3(const bary_deriv* b, v3 a0, v3 a1, v3 a2) {
@@ -534,19 +534,18 @@ static v3 shade_pixel(const rdr_scene_desc* s, const rdr_ubo* u, const env_ctx* 
 
     v4 p1 = {v1->p[0], v1->p[1], v1->p[2], 1.0f}, p2 = {v2->p[0], v2->p[1], v2->p[2], 1.0f},
        p3 = {v3p->p[0], v3p->p[1], v3p->p[2], 1.0f};
-    v4 w1 = m4_mul_v4(model, p1), w2 = m4_mul_v4(model, p2), w3 = m4_mul_v4(model, p3);
-    v4 c1 = m4_mul_v4(u->view_proj, w1), c2 = m4_mul_v4(u->view_proj, w2), c3 = m4_mul_v4(u->view_proj, w3);
+    v4 w1 = m4_mul_v4_fma(model, p1), w2 = m4_mul_v4_fma(model, p2), w3 = m4_mul_v4_fma(model, p3);
+    v4 c1 = m4_mul_v4_fma(u->view_proj, w1), c2 = m4_mul_v4_fma(u->view_proj, w2), c3 = m4_mul_v4_fma(u->view_proj, w3);
 
     bary_deriv bary = calc_full_bary(c1, c2, c3, uvx * 2.0f - 1.0f, uvy * 2.0f - 1.0f,
                                      u->screen_width, u->screen_height);
 
     v3 w_pos = interp_v3(&bary, v3_make(w1.x, w1.y, w1.z), v3_make(w2.x, w2.y, w2.z), v3_make(w3.x, w3.y, w3.z));
-    v3 norm = interp_v3(&bary, m4_mul_dir(model, v3_make(v1->n[0], v1->n[1], v1->n[2])),
-                        m4_mul_dir(model, v3_make(v2->n[0], v2->n[1], v2->n[2])),
-                        m4_mul_dir(model, v3_make(v3p->n[0], v3p->n[1], v3p->n[2])));
-    v3 tangent = interp_v3(&bary, m4_mul_dir(model, v3_make(v1->t[0], v1->t[1], v1->t[2])),
-                           m4_mul_dir(model, v3_make(v2->t[0], v2->t[1], v2->t[2])),
-                           m4_mul_dir(model, v3_make(v3p->t[0], v3p->t[1], v3p->t[2])));
+    /* mat3(model) applied to the interpolated vector (linear either way; the GPU path does the same) */
+    v3 norm = m4_mul_dir_fma(model, interp_v3(&bary, v3_make(v1->n[0], v1->n[1], v1->n[2]), v3_make(v2->n[0], v2->n[1], v2->n[2]),
+                                              v3_make(v3p->n[0], v3p->n[1], v3p->n[2])));
+    v3 tangent = m4_mul_dir_fma(model, interp_v3(&bary, v3_make(v1->t[0], v1->t[1], v1->t[2]), v3_make(v2->t[0], v2->t[1], v2->t[2]),
+                                                 v3_make(v3p->t[0], v3p->t[1], v3p->t[2])));
     interp1 iu = interp_scalar(&bary, v1->uv[0], v2->uv[0], v3p->uv[0]);
     interp1 iv = interp_scalar(&bary, v1->uv[1], v2->uv[1], v3p->uv[1]);
     /* uv1 is built from .xy as well (shading.frag.glsl:373-374), so uv_index never matters */

@@ -47,9 +47,9 @@ static inline v4 orc_decode_texel(const uint8_t* p, uint32_t format) {
     return r;
 }
 
+/* a + t (b - a) with the product and the sum fused, as the GPU sampler evaluates it */
 static inline v4 v4_lerp(v4 a, v4 b, float t) {
-    float s = 1.0f - t;
-    v4 r = {a.x * s + b.x * t, a.y * s + b.y * t, a.z * s + b.z * t, a.w * s + b.w * t};
+    v4 r = {fmaf(t, b.x - a.x, a.x), fmaf(t, b.y - a.y, a.y), fmaf(t, b.z - a.z, a.z), fmaf(t, b.w - a.w, a.w)};
     return r;
 }
 
@@ -104,9 +104,9 @@ static inline v4 orc_image_sample_grad(const rdr_image_desc* im, float u, float 
                                        float dvdx, float dudy, float dvdy) {
     float w = (float)im->width, h = (float)im->height;
     float ax = dudx * w, ay = dvdx * h, bx = dudy * w, by = dvdy * h;
-    float rx = sqrtf(ax * ax + ay * ay), ry = sqrtf(bx * bx + by * by);
-    float rho = fmaxf(rx, ry);
-    float lod = log2f(rho);
+    /* log2 of the longer footprint axis, as half the log2 of its squared length */
+    float rho2 = fmaxf(ax * ax + ay * ay, bx * bx + by * by);
+    float lod = 0.5f * log2f(rho2);
     return orc_image_sample_lod(im, u, v, lod);
 }
 

@@ -63,6 +63,24 @@ RDR_DEV vec3 mul_m3(const float* m, vec3 v) {
                (m[2] * v.x + m[6] * v.y) + m[10] * v.z);
 }
 
+// The list passes' forms of the three products above, with fused multiply-adds: one rounding per term instead of
+// two, and four instructions per row instead of seven.  GLSL leaves contraction to the compiler; the rasterisers
+// keep the unfused forms, which the bit-exact visibility keys are defined with.  The CPU checker evaluates the same
+// expressions with fmaf().
+RDR_DEV float dot3_fma(vec3 a, vec3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+RDR_DEV vec4 mul_m4_fma(const float* m, vec4 v) {
+    vec4 r;
+    r.x = fmaf(m[12], v.w, fmaf(m[8], v.z, fmaf(m[4], v.y, m[0] * v.x)));
+    r.y = fmaf(m[13], v.w, fmaf(m[9], v.z, fmaf(m[5], v.y, m[1] * v.x)));
+    r.z = fmaf(m[14], v.w, fmaf(m[10], v.z, fmaf(m[6], v.y, m[2] * v.x)));
+    r.w = fmaf(m[15], v.w, fmaf(m[11], v.z, fmaf(m[7], v.y, m[3] * v.x)));
+    return r;
+}
+RDR_DEV vec3 mul_m3_fma(const float* m, vec3 v) {
+    return mk3(fmaf(m[8], v.z, fmaf(m[4], v.y, m[0] * v.x)), fmaf(m[9], v.z, fmaf(m[5], v.y, m[1] * v.x)),
+               fmaf(m[10], v.z, fmaf(m[6], v.y, m[2] * v.x)));
+}
+
 // Load a 4x4 matrix whose address is the same in every lane of the wave.
 RDR_DEV void load_m4(const float* p, float* m) {
 #pragma unroll
@@ -134,9 +152,9 @@ RDR_DEV vec4 decode_texel(const uint8_t* p, uint32_t format, const float* srgb_l
     return mk4(unorm8(r), unorm8(g), unorm8(b), unorm8(a));
 }
 
+// a + t (b - a), the product and the sum fused: two instructions per channel
 RDR_DEV vec4 lerp4(vec4 a, vec4 b, float t) {
-    const float s = 1.0f - t;
-    return mk4(a.x * s + b.x * t, a.y * s + b.y * t, a.z * s + b.z * t, a.w * s + b.w * t);
+    return mk4(fmaf(t, b.x - a.x, a.x), fmaf(t, b.y - a.y, a.y), fmaf(t, b.z - a.z, a.z), fmaf(t, b.w - a.w, a.w));
 }
 
 RDR_DEV int wrap_repeat(int i, int n) {
@@ -218,9 +236,9 @@ RDR_DEV vec4 image_sample_grad(const GpuImage& im, const uint8_t* texels, const 
                                float dudx, float dvdx, float dudy, float dvdy, bool lut_linear = false) {
     const float w = (float)im.width, h = (float)im.height;
     const float ax = dudx * w, ay = dvdx * h, bx = dudy * w, by = dvdy * h;
-    // max(sqrt(a), sqrt(b)) == sqrt(max(a, b)): the correctly rounded square root is monotonic
-    const float rho = sqrtf(fmaxf(ax * ax + ay * ay, bx * bx + by * by));
-    return image_sample_lod(im, texels, lut, u, v, log2f(rho), lut_linear);
+    // log2 of the longer footprint axis = half the log2 of its squared length: no square root
+    const float rho2 = fmaxf(ax * ax + ay * ay, bx * bx + by * by);
+    return image_sample_lod(im, texels, lut, u, v, 0.5f * log2f(rho2), lut_linear);
 }
 
 // ---- cubemaps ------------------------------------------------------------------

@@ -66,8 +66,8 @@ RDR_DEV BaryDeriv calc_full_bary(vec4 pt0, vec4 pt1, vec4 pt2, float ndcx, float
 }
 
 RDR_DEV vec3 interp3(const BaryDeriv& b, vec3 a0, vec3 a1, vec3 a2) {
-    return mk3(dot3(mk3(a0.x, a1.x, a2.x), b.lambda), dot3(mk3(a0.y, a1.y, a2.y), b.lambda),
-               dot3(mk3(a0.z, a1.z, a2.z), b.lambda));
+    return mk3(dot3_fma(mk3(a0.x, a1.x, a2.x), b.lambda), dot3_fma(mk3(a0.y, a1.y, a2.y), b.lambda),
+               dot3_fma(mk3(a0.z, a1.z, a2.z), b.lambda));
 }
 
 RDR_DEV vec3 vload3(const float* p) { return mk3(p[0], p[1], p[2]); }

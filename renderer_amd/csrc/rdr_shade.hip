@@ -169,19 +169,21 @@ RDR_DEV vec3 shade_pixel(const SceneView& sv, const float* srgb, const FrameView
     const rdr_vertex* v2 = &sv.vertices[px.i2];
     const rdr_vertex* v3 = &sv.vertices[px.i3];
 
-    const vec4 w1 = mul_m4(model, mk4(v1->p[0], v1->p[1], v1->p[2], 1.0f));
-    const vec4 w2 = mul_m4(model, mk4(v2->p[0], v2->p[1], v2->p[2], 1.0f));
-    const vec4 w3 = mul_m4(model, mk4(v3->p[0], v3->p[1], v3->p[2], 1.0f));
-    const vec4 c1 = mul_m4(u.view_proj, w1), c2 = mul_m4(u.view_proj, w2), c3 = mul_m4(u.view_proj, w3);
+    const vec4 w1 = mul_m4_fma(model, mk4(v1->p[0], v1->p[1], v1->p[2], 1.0f));
+    const vec4 w2 = mul_m4_fma(model, mk4(v2->p[0], v2->p[1], v2->p[2], 1.0f));
+    const vec4 w3 = mul_m4_fma(model, mk4(v3->p[0], v3->p[1], v3->p[2], 1.0f));
+    const vec4 c1 = mul_m4_fma(u.view_proj, w1), c2 = mul_m4_fma(u.view_proj, w2), c3 = mul_m4_fma(u.view_proj, w3);
     const BaryDeriv bary = calc_full_bary(c1, c2, c3, uvx * 2.0f - 1.0f, uvy * 2.0f - 1.0f, fv.two_over_width, fv.two_over_height);
 
     const vec3 w_pos = interp3(bary, mk3(w1.x, w1.y, w1.z), mk3(w2.x, w2.y, w2.z), mk3(w3.x, w3.y, w3.z));
-    const vec3 norm = interp3(bary, mul_m3(model, vload3(v1->n)), mul_m3(model, vload3(v2->n)), mul_m3(model, vload3(v3->n)));
-    const vec3 tangent = interp3(bary, mul_m3(model, vload3(v1->t)), mul_m3(model, vload3(v2->t)), mul_m3(model, vload3(v3->t)));
+    // mat3(model) is applied to the interpolated vector, not to the three it is interpolated from: the same
+    // value but for rounding (both steps are linear), and a third of the products
+    const vec3 norm = mul_m3_fma(model, interp3(bary, vload3(v1->n), vload3(v2->n), vload3(v3->n)));
+    const vec3 tangent = mul_m3_fma(model, interp3(bary, vload3(v1->t), vload3(v2->t), vload3(v3->t)));
     const vec3 us = mk3(v1->uv[0], v2->uv[0], v3->uv[0]), vs = mk3(v1->uv[1], v2->uv[1], v3->uv[1]);
     // uv1 is interpolated from .xy as well (shading.frag.glsl:373-374): the uv index never matters
-    const InterpUv uv0 = {dot3(us, bary.lambda), dot3(vs, bary.lambda), dot3(us, bary.ddx), dot3(vs, bary.ddx),
-                          dot3(us, bary.ddy), dot3(vs, bary.ddy)};
+    const InterpUv uv0 = {dot3_fma(us, bary.lambda), dot3_fma(vs, bary.lambda), dot3_fma(us, bary.ddx), dot3_fma(vs, bary.ddx),
+                          dot3_fma(us, bary.ddy), dot3_fma(vs, bary.ddy)};
 
     const vec4 one = mk4(1.0f, 1.0f, 1.0f, 1.0f), nmap_def = mk4(0.5f, 0.5f, 1.0f, 0.0f);
     vec4 albedo = sample_or_default(sv, srgb, mat.albedo_texture,

@@ -340,10 +340,10 @@ RDR_DEV vec3 pixel_world_position(const SceneView& sv, const rdr_ubo& u, float t
     const float* q1 = sv.vertices[p.i1].p;
     const float* q2 = sv.vertices[p.i2].p;
     const float* q3 = sv.vertices[p.i3].p;
-    const vec4 w1 = mul_m4(model, mk4(q1[0], q1[1], q1[2], 1.0f));
-    const vec4 w2 = mul_m4(model, mk4(q2[0], q2[1], q2[2], 1.0f));
-    const vec4 w3 = mul_m4(model, mk4(q3[0], q3[1], q3[2], 1.0f));
-    const vec4 c1 = mul_m4(u.view_proj, w1), c2 = mul_m4(u.view_proj, w2), c3 = mul_m4(u.view_proj, w3);
+    const vec4 w1 = mul_m4_fma(model, mk4(q1[0], q1[1], q1[2], 1.0f));
+    const vec4 w2 = mul_m4_fma(model, mk4(q2[0], q2[1], q2[2], 1.0f));
+    const vec4 w3 = mul_m4_fma(model, mk4(q3[0], q3[1], q3[2], 1.0f));
+    const vec4 c1 = mul_m4_fma(u.view_proj, w1), c2 = mul_m4_fma(u.view_proj, w2), c3 = mul_m4_fma(u.view_proj, w3);
     const BaryDeriv bary = calc_full_bary(c1, c2, c3, p.uvx * 2.0f - 1.0f, p.uvy * 2.0f - 1.0f, two_over_width, two_over_height);
     face_normal = cross3(mk3(w2.x - w1.x, w2.y - w1.y, w2.z - w1.z), mk3(w3.x - w1.x, w3.y - w1.y, w3.z - w1.z));
     return interp3(bary, mk3(w1.x, w1.y, w1.z), mk3(w2.x, w2.y, w2.z), mk3(w3.x, w3.y, w3.z));
