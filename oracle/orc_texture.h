@@ -185,7 +185,8 @@ static inline v4 orc_cube_bilinear(const rdr_cubemap_desc* cm, uint32_t level, v
     float sc, tc, ma;
     int face = cube_face(d, &sc, &tc, &ma);
     int n = (int)mip_dim(cm->size, level);
-    float s = 0.5f * (sc / ma + 1.0f), t = 0.5f * (tc / ma + 1.0f);
+    float inv_ma = 1.0f / ma; /* one reciprocal for both face coordinates, as on the GPU */
+    float s = 0.5f * (sc * inv_ma + 1.0f), t = 0.5f * (tc * inv_ma + 1.0f);
     float x = s * (float)n - 0.5f, y = t * (float)n - 0.5f;
     float fx = floorf(x), fy = floorf(y);
     float ax = x - fx, ay = y - fy;

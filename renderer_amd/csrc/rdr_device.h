@@ -266,7 +266,8 @@ RDR_DEV vec4 cube_bilinear(const GpuCubemap& cm, const uint8_t* texels, uint32_t
     float sc, tc, ma;
     const int face = cube_face(d, sc, tc, ma);
     const int n = (int)mip_dim(cm.size, level);
-    const float s = 0.5f * (sc / ma + 1.0f), t = 0.5f * (tc / ma + 1.0f);
+    const float inv_ma = 1.0f / ma; // one reciprocal for both face coordinates
+    const float s = 0.5f * (sc * inv_ma + 1.0f), t = 0.5f * (tc * inv_ma + 1.0f);
     const float x = s * (float)n - 0.5f, y = t * (float)n - 0.5f;
     const float fx = floorf(x), fy = floorf(y);
     const float ax = x - fx, ay = y - fy;
