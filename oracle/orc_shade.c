@@ -23,6 +23,12 @@
  * derivatives); pow(x, 5) and pow(x, 2) are exact products; the ray/triangle
  * test is watertight (as the ray query is), in object space with the instance
  * transform inverted in double precision; a ray hits when tmin < t < tmax.
+ * GLSL fixes neither the rounding of normalize() nor contraction nor the order of
+ * linear steps; the forms chosen (and evaluated identically by the GPU path, every
+ * operation correctly rounded): normalize(x) = x * (1 / sqrt(x.x)); fmaf chains for
+ * the matrix products and three-term dot products of this pass; mat3(model) applied
+ * to the interpolated normal and tangent; texel blends a + t (b - a) with the product
+ * fused; LOD = 0.5 * log2 of the squared footprint axis.
  */
 #include <stdlib.h>
 #include <stdio.h>
