@@ -151,6 +151,46 @@ def test_bc7_cubemap_file_is_expanded_with_the_library_decode(tmp_path, oracle):
         load_cubemap_ktx2(path)
 
 
+@pytest.mark.gpu
+def test_env_json_with_a_bc7_skybox_feeds_the_skybox_pass(tmp_path, oracle):
+    """The reference's environment description names a skybox file of BC7 blocks (bake/src/cubemaps.rs:158-163): read
+    through load_env_json it must give the skybox pass the texels the CPU decode gives."""
+    from renderer_amd import Renderer, RendererConfig
+    from renderer_amd.scene import Camera
+    env = synth.default_env()
+    save_env_json(tmp_path / "env.json", env)
+    rng = np.random.default_rng(11)
+    n = 32
+    levels = _bc7_levels(rng, 6, n, n, 3)
+    write_ktx2_blocks(tmp_path / "env_skybox.ktx2", levels, n, n)
+    back = load_env_json(tmp_path / "env.json")
+    want = []
+    for l, lv in enumerate(levels):
+        m = max(1, n >> l)
+        faces = np.zeros((6, m, m, 4), np.uint8)
+        for f in range(6):
+            blocks = np.ascontiguousarray(lv[f])
+            assert oracle.lib().orc_decode_bc(abi.FORMAT_BC7, m, m, 1, blocks.ctypes.data_as(C.c_void_p), faces[f].ctypes.data_as(C.c_void_p)) == 0
+        want.append(faces)
+    assert all(np.array_equal(a, b) for a, b in zip(back.skybox.mips, want))
+    sc = synth.make_triangle_scene([(0, 0, 5), (1, 0, 5), (0, 1, 5)])
+    sc.env = back
+    W, H = 96, 64
+    conf = RendererConfig(skybox=True)
+    r = Renderer(W, H, conf)
+    r.set_scene(sc)
+    cam = Camera((0.0, 0.0, 0.0), (0.3, 0.2, 1.0))
+    r.render(cam)
+    got = r.read_color()
+    r.close()
+    o = oracle.OracleRenderer(W, H, conf)
+    o.set_scene(sc)
+    o.render_visbuffer(cam)
+    ref = o.shade()
+    assert int(np.abs(got.astype(int) - ref.astype(int)).max()) <= 2
+    assert len(np.unique(got.reshape(-1, 4), axis=0)) > 50  # the random sky shows
+
+
 def test_env_json_round_trip(tmp_path):
     env = synth.default_env()
     save_env_json(tmp_path / "env.json", env)
