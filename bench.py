@@ -9,10 +9,11 @@ icosphere field at 3840x2160 ("Field-S": 1 250 instances x 20 480 triangles = 25
 per GPU), the stand-in for the Sponza / Bistro configurations whose assets do not ship with the
 reference.  With N > 1 there is one process per GPU: started by torch.distributed.run, or, when
 WORLD_SIZE is not set, by this script itself, which then spawns its N ranks as fresh child
-processes before anything touches a GPU.  Every rank holds the whole scene and rasterises its
-contiguous share of the meshlet instances; the full-frame visibility buffers are composited with a
-64-bit MIN (reduce-scatter by row strips over RCCL), every rank shades H/N rows and the RGBA8 rows
-are all-gathered.  ``--scaling strong`` (the default) renders the same field at every N, ``weak``
+processes before anything touches a GPU.  Every rank holds the whole scene and rasterises its share
+of the meshlet instances (chunks of 64 meshlets dealt round-robin, ``--split interleaved``, or a
+contiguous N-th); the full-frame visibility buffers are composited with a 64-bit MIN (peer to peer
+over xGMI, or an RCCL reduce-scatter), every rank shades its rows (32-row bands dealt round-robin, or
+a contiguous strip) and the RGBA8 rows are gathered.  ``--scaling strong`` (the default) renders the same field at every N, ``weak``
 an N-times larger one.  Rank 0 prints one JSON line.
 """
 import argparse
@@ -183,6 +184,8 @@ def main():
     ap.add_argument("--composite", choices=("auto", "p2p", "reduce_scatter", "all_reduce"), default="auto",
                     help="exchange step of the sort-last composite (auto: the library's peer-to-peer exchange over xGMI when "
                          "the ranks can open each other's buffers and a probe frame matches the collective, else RCCL reduce-scatter)")
+    ap.add_argument("--split", choices=("interleaved", "contiguous"), default="interleaved",
+                    help="multi-GPU only: how meshlet instances and rows are dealt to the ranks")
     ap.add_argument("--frames-in-flight", type=int, default=int(os.environ.get("RDR_FRAMES_IN_FLIGHT", "2")),
                     help="multi-GPU only: renderers taking turns so that one frame's exchange overlaps the next frame's raster")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
@@ -236,9 +239,11 @@ def main():
     tris_per_frame = scene.triangle_count()
     # occlusion culling (cull_enabled) never changes the image; on this scene nothing hides behind anything, so the
     # second phase and the depth pyramid would only cost time (series "occlusion culling on" below)
-    # kernel durations come from event brackets inside the timed region; bracketing costs about 33 us per frame (5 % of
-    # this frame), so every 8th frame is bracketed and the other seven run as a caller without timers runs them
-    conf = RendererConfig(lod_enabled=False, cull_enabled=False, collect_stats=True, time_kernels=8)
+    # kernel durations come from event brackets inside the timed region; bracketing costs about 33 us per frame (8 % of
+    # this frame), so only every n-th frame is bracketed and the others run as a caller without timers runs them:
+    # every 8th, or more often when the run is short, so that at least five frames are bracketed
+    bracket_every = min(8, max(1, args.steps // 5))
+    conf = RendererConfig(lod_enabled=False, cull_enabled=False, collect_stats=True, time_kernels=bracket_every)
     def make_renderer():
         rr = Renderer(W, H, conf, device=local_rank)
         rr.set_scene(scene)
@@ -248,7 +253,7 @@ def main():
     if multi:
         from renderer_amd.distributed import SortLastPipeline
         frame = SortLastPipeline(make_renderer, scene.meshlet_visibility_count, H, rank, world,
-                                 depth=args.frames_in_flight, composite=args.composite)
+                                 depth=args.frames_in_flight, composite=args.composite, split=args.split)
         r = frame.renderers()[0]
     else:
         r = make_renderer()
@@ -299,6 +304,7 @@ def main():
         # same workload, and the line says so (traffic_source)
         traffic = None
         issue = None
+        raster_issue = None
         traffic_source = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
@@ -307,6 +313,7 @@ def main():
                 if rec.get("workload") == [args.instances, args.subdivisions, W, H] and world == 1:
                     traffic = rec.get("kernels", {}).get(dom)
                     issue = rec.get("issue", {}).get(dom)
+                    raster_issue = rec.get("issue", {}).get("raster")
                     traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of profiles/refresh_r2.sh, committed; not this run)"
             except Exception:
                 traffic = None
@@ -332,12 +339,13 @@ def main():
                 "instances": total_instances, "width": W, "height": H,
                 "ranks": dist.get_world_size() if multi else 1, "backend": (dist.get_backend() if multi else None),
                 "parallelism": "single GPU" if frame is None else
-                               f"sort-last x{world}, u64-min {frame.composite.replace('_', '-')} + row-split shade + RGBA8 row gather, "
+                               f"sort-last x{world} ({args.split} shares), u64-min {frame.composite.replace('_', '-')} + row-split shade + RGBA8 row gather, "
                                f"{len(frame.slots)} frames in flight" + ("" if args.backend == "nccl" else " [gloo rehearsal]"),
             },
             "kernel_ms": {k: round(v, 4) for k, v in kms.items() if v > 0},
             # the brackets tile the frame (each spans its group of launches, dependency latency included) and are taken on
-            # every 8th frame, which they lengthen by about 33 us: the difference to ms_per_step is that and the host's gaps
+            # every n-th frame, which they lengthen by about 33 us: the difference to ms_per_step is that and the host's gaps
+            "kernel_ms_frames": st["frames_timed"], "kernel_ms_every": bracket_every,
             "kernel_ms_sum": round(sum(kms.values()), 4),
             "frame_minus_kernels_ms": round(ms - sum(kms.values()), 4),
             "launches_per_frame": {"all_opaque_no_occlusion": 10, "with_alpha_tested_draws": 12,
@@ -367,6 +375,22 @@ def main():
             out["raster_atomics"] = {"fragments": st["fragments"], "per_s": st["fragments"] / raster_s,
                                      "bytes_per_s": st["fragments"] * 8 / raster_s,
                                      "note": "64-bit atomicMin issued per fragment by k_raster / k_mid_raster; the tile path merges without atomics"}
+            try:
+                # the ceiling, measured now on this GPU: a kernel that does nothing but issue the same atomic in the per-lane
+                # scan's address pattern (64 boxes of 2 x 2 pixels scattered over 32 x 32 pixels per wave; profiles/atomic_peak.hip)
+                sys.path.insert(0, os.path.join(ROOT, "profiles"))
+                import atomic_peak
+                torch.cuda.synchronize()
+                peak = atomic_peak.rates(local_rank, repeats=3, full=False)["box_2x2_region32"] * 1e9
+                if peak > 0:
+                    out["raster_atomics"].update({"peak": peak, "frac": st["fragments"] / raster_s / peak, "unit": "atomics/s",
+                                                  "peak_source": "profiles/atomic_peak.hip, pattern box_2x2_region32, measured in this run"})
+                    # which of its two limits the rasteriser is closer to
+                    issue_frac = (raster_issue or {}).get("valu_busy")  # share of the vector issue slots k_raster uses (committed PMC record)
+                    out["raster_atomics"]["closer_to"] = ("vector issue" if issue_frac is not None and issue_frac > out["raster_atomics"]["frac"]
+                                                          else "atomic rate" if issue_frac is not None else None)
+            except Exception as e:  # the helper library is optional
+                out["raster_atomics"]["peak_error"] = str(e)
         if world == 1 and frame is None and args.secondary_frames > 0:
             out["secondary"] = secondary_series(W, H, args.secondary_frames, args.instances, args.subdivisions)
         if world == 1 and args.cpu_frames > 0:

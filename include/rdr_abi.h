@@ -336,6 +336,22 @@ int rdr_set_partition(rdr_renderer* r, uint32_t instance_lo, uint32_t instance_h
 /* Shading restricted to rows [row_lo, row_hi) (after a reduce-scatter). Default all. */
 int rdr_set_shade_rows(rdr_renderer* r, uint32_t row_lo, uint32_t row_hi);
 
+/* The balanced forms of the two calls above (no counterpart in the reference, which is single-GPU;
+ * the id order they deal out is the draw order of scenery/src/scene.rs:648-651, which for an
+ * instanced scene is a spatial order, so contiguous N-ths give one rank the near instances and
+ * another the far ones).
+ * rdr_set_partition_interleaved: the meshlets of every draw are cut into chunks of `chunk`
+ * consecutive meshlets (of the level of detail the draw selected; chunk = a multiple of 64, at most
+ * 2^20), and chunk j of draw d belongs to rank (j + d) % world.  Every meshlet instance belongs to
+ * exactly one rank, so the 64-bit minimum over the ranks' buffers is the single-GPU buffer.  The
+ * range of rdr_set_partition still applies on top (default: everything); world = 1 switches the
+ * interleaving off.
+ * rdr_set_shade_bands: the frame's rows are cut into bands of `band` rows (a power of two, at
+ * least 32: the exchange works on 32 x 32 tiles), and band b belongs to rank b % world.  Replaces
+ * the row range of rdr_set_shade_rows, and rdr_set_shade_rows replaces it. */
+int rdr_set_partition_interleaved(rdr_renderer* r, uint32_t chunk, uint32_t rank, uint32_t world);
+int rdr_set_shade_bands(rdr_renderer* r, uint32_t band, uint32_t rank, uint32_t world);
+
 /* Device addresses of the W*H uint64 visibility buffer and the W*H*4 RGBA8
  * image, for the collective that composites them (RCCL through the caller). */
 void* rdr_visbuffer_device_ptr(rdr_renderer* r);

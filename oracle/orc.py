@@ -32,6 +32,8 @@ def lib():
         L.orc_build_ubo.restype = None
         L.orc_render_visbuffer.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.Ubo), C.c_uint32, C.c_uint32,
                                            C.c_void_p, C.c_void_p, C.POINTER(abi.Stats)]
+        L.orc_render_visbuffer_interleaved.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.Ubo), C.c_uint32, C.c_uint32,
+                                                       C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(abi.Stats)]
         L.orc_resolve.argtypes = [C.POINTER(abi.SceneDesc), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_shade.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.Ubo), C.c_void_p, C.c_void_p, C.c_uint32,
                                 C.c_uint32, C.c_void_p, C.c_void_p]
@@ -64,6 +66,7 @@ class OracleRenderer:
         self.cull_enabled = bool(config.cull_enabled) if config else True
         self.skybox = bool(getattr(config, "skybox", False)) if config else False
         self.part = (0, 0xFFFFFFFF)
+        self.interleave = (64, 0, 1)  # chunk, rank, world
         self.stats = abi.Stats()
 
     def set_scene(self, scene):
@@ -74,28 +77,37 @@ class OracleRenderer:
     def set_partition(self, lo, hi):
         self.part = (lo, hi)
 
+    def set_partition_interleaved(self, chunk, rank, world):
+        self.interleave = (chunk, rank, world)
+
     def render_visbuffer(self, camera=None, sun=None):
         cam = camera or self.scene.camera
         sun = sun or self.scene.sun_direction
         self.ubo = build_ubo(self.width, self.height, cam.position, cam.direction, sun,
                              len(self.scene.mesh_draws), self.lod_enabled, self.cull_enabled)
         self.vis = np.empty(self.width * self.height, np.uint64)
-        rc = lib().orc_render_visbuffer(C.byref(self.desc), C.byref(self.ubo), self.part[0], self.part[1],
-                                        self.vis.ctypes.data, self.draw_lod.ctypes.data, C.byref(self.stats))
+        rc = lib().orc_render_visbuffer_interleaved(C.byref(self.desc), C.byref(self.ubo), self.part[0], self.part[1],
+                                                    *self.interleave, self.vis.ctypes.data, self.draw_lod.ctypes.data,
+                                                    C.byref(self.stats))
         assert rc == 0
         return self.vis.reshape(self.height, self.width)
 
-    def shade(self, vis=None, rows=None, want_linear=False):
+    def shade(self, vis=None, rows=None, want_linear=False, bands=None):
+        """``rows`` = (lo, hi), or ``bands`` = (band, rank, world): the rows of rdr_set_shade_bands."""
         vis = self.vis if vis is None else np.ascontiguousarray(vis, np.uint64).reshape(-1)
-        rows = rows or (0, self.height)
+        spans = [rows or (0, self.height)]
+        if bands:
+            band, rank, world = bands
+            spans = [(lo, min(lo + band, self.height)) for lo in range(rank * band, self.height, band * world)]
         out = np.zeros((self.height, self.width, 4), np.uint8)
         lin = np.zeros((self.height, self.width, 4), np.float32) if want_linear else None
-        rc = lib().orc_shade(C.byref(self.desc), C.byref(self.ubo), vis.ctypes.data, self.draw_lod.ctypes.data,
-                             rows[0], rows[1], out.ctypes.data, lin.ctypes.data if want_linear else None)
-        assert rc == 0
-        if self.skybox:
-            rc = lib().orc_skybox(C.byref(self.desc), C.byref(self.ubo), vis.ctypes.data, rows[0], rows[1], out.ctypes.data)
+        for lo, hi in spans:
+            rc = lib().orc_shade(C.byref(self.desc), C.byref(self.ubo), vis.ctypes.data, self.draw_lod.ctypes.data,
+                                 lo, hi, out.ctypes.data, lin.ctypes.data if want_linear else None)
             assert rc == 0
+            if self.skybox:
+                rc = lib().orc_skybox(C.byref(self.desc), C.byref(self.ubo), vis.ctypes.data, lo, hi, out.ctypes.data)
+                assert rc == 0
         return (out, lin) if want_linear else out
 
     def render(self, camera=None, sun=None):

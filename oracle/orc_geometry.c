@@ -443,6 +443,16 @@ static void make_alpha_test(const rdr_scene_desc* s, const rdr_mesh_draw* d, alp
 
 int orc_render_visbuffer(const rdr_scene_desc* s, const rdr_ubo* u, uint32_t part_lo,
                          uint32_t part_hi, uint64_t* vis, uint8_t* draw_lod, rdr_stats* stats) {
+    return orc_render_visbuffer_interleaved(s, u, part_lo, part_hi, 64, 0, 1, vis, draw_lod, stats);
+}
+
+/* The sort-last share of rdr_set_partition_interleaved on top of the range: chunk j of draw d
+ * (chunks of `chunk` consecutive meshlets of the selected level of detail) belongs to rank
+ * (j + d) % world. */
+int orc_render_visbuffer_interleaved(const rdr_scene_desc* s, const rdr_ubo* u, uint32_t part_lo,
+                                     uint32_t part_hi, uint32_t chunk, uint32_t rank, uint32_t world,
+                                     uint64_t* vis, uint8_t* draw_lod, rdr_stats* stats) {
+    if (chunk == 0 || world == 0 || rank >= world) return 1;
     orc_srgb_lut_init();
     int W = (int)u->screen_width, H = (int)u->screen_height;
     size_t npx = (size_t)W * H;
@@ -470,6 +480,7 @@ int orc_render_visbuffer(const rdr_scene_desc* s, const rdr_ubo* u, uint32_t par
         for (uint32_t k = 0; k < L->meshlet_count; ++k) {
             uint32_t instance = d->meshlet_visibility_offset + k;
             if (instance < part_lo || instance >= part_hi) continue;
+            if (world > 1 && (k / chunk + (uint32_t)di) % world != rank) continue;
             uint32_t mi = L->meshlet_offset + k;
             tris_submitted += s->meshlets[mi].triangle_count;
             meshlets_tested++;

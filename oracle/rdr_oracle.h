@@ -23,6 +23,10 @@ void orc_build_ubo(uint32_t width, uint32_t height, const float cam_pos[3], cons
  * selected, 0xFF for draws that emitted nothing. */
 int orc_render_visbuffer(const rdr_scene_desc* scene, const rdr_ubo* ubo, uint32_t part_lo,
                          uint32_t part_hi, uint64_t* vis, uint8_t* draw_lod, rdr_stats* stats);
+/* The same with the interleaved share of rdr_set_partition_interleaved on top of the range. */
+int orc_render_visbuffer_interleaved(const rdr_scene_desc* scene, const rdr_ubo* ubo, uint32_t part_lo,
+                                     uint32_t part_hi, uint32_t chunk, uint32_t rank, uint32_t world,
+                                     uint64_t* vis, uint8_t* draw_lod, rdr_stats* stats);
 
 int orc_resolve(const rdr_scene_desc* scene, uint32_t width, uint32_t height, const uint64_t* vis,
                 const uint8_t* draw_lod, uint32_t* out_xy);

@@ -135,6 +135,8 @@ struct rdr_renderer {
     rdr_ubo ubo{};
     uint32_t part_lo = 0, part_hi = 0xFFFFFFFFu;
     uint32_t row_lo = 0, row_hi = 0xFFFFFFFFu;
+    uint32_t part_chunk = 64, part_rank = 0, part_world = 1; // rdr_set_partition_interleaved
+    uint32_t band_shift = 5, band_rank = 0, band_world = 1;  // rdr_set_shade_bands
     uint32_t meshlet_visibility_count = 0;
     uint32_t lds_stack_limit = 24;
     GeometryResidency resident{};
@@ -404,8 +406,11 @@ FrameView make_frame_view(rdr_renderer* r) {
     }
     fv.width = r->width; fv.height = r->height;
     fv.part_lo = r->part_lo; fv.part_hi = r->part_hi;
+    fv.part_chunk = r->part_chunk; fv.part_rank = r->part_rank; fv.part_world = r->part_world;
     fv.row_lo = std::min(r->row_lo, r->height);
     fv.row_hi = std::min(r->row_hi, r->height);
+    fv.band_shift = r->band_shift; fv.band_rank = r->band_rank; fv.band_world = r->band_world;
+    fv.shade_rows = r->band_world > 1u ? rdr_band_rows(r->height, r->band_shift, r->band_rank, r->band_world) : fv.row_hi - fv.row_lo;
     fv.command_capacity = (uint32_t)r->commands.count;
     fv.visible_capacity = (uint32_t)r->visible.count;
     fv.deferred_capacity = (uint32_t)r->deferred.count;
@@ -476,7 +481,7 @@ FrameView make_frame_view(rdr_renderer* r) {
     g.mid_blocks = std::max(1u, r->resident.mid_raster);
     g.frag_blocks = r->masked_meshlets ? std::max(1u, r->resident.alpha_frag) : 1u;
     g.shade_blocks_x = (r->width + 15u) / 16u;
-    g.shade_blocks_y = (fv.row_hi - fv.row_lo + 15u) / 16u;
+    g.shade_blocks_y = (fv.shade_rows + 15u) / 16u;
     g.slot_draw = 0;
     g.slot_cull = g.slot_draw + g.draw_blocks;
     g.slot_raster = g.slot_cull + g.cull_blocks * kCullSlots;
@@ -499,6 +504,10 @@ int fetch_counters(rdr_renderer* r, FrameCounters* out) {
     RDR_CHECK(out->cmd_count <= r->commands.count && (uint64_t)out->vis_count + out->vis_mask_count <= r->visible.count,
               "frame: a work list overflowed");
     return 0;
+}
+
+RowSet shaded_rows(const rdr_renderer* r) {
+    return RowSet{std::min(r->row_lo, r->height), std::min(r->row_hi, r->height), r->band_shift, r->band_rank, r->band_world};
 }
 
 std::string status_message(uint32_t flags) {
@@ -760,10 +769,10 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
     {
         // statistics slots for the largest launch geometry this scene can produce
         r->sv.draw_count = s.draw_count;
-        const uint32_t keep_lo = r->row_lo, keep_hi = r->row_hi;
-        r->row_lo = 0; r->row_hi = r->height;
+        const uint32_t keep_lo = r->row_lo, keep_hi = r->row_hi, keep_world = r->band_world;
+        r->row_lo = 0; r->row_hi = r->height; r->band_world = 1;
         const FrameView fv = make_frame_view(r);
-        r->row_lo = keep_lo; r->row_hi = keep_hi;
+        r->row_lo = keep_lo; r->row_hi = keep_hi; r->band_world = keep_world;
         if (r->stat_slots.alloc(fv.grid.slot_total)) return 1;
         RDR_HIP(hipMemset(r->stat_slots.ptr, 0, (size_t)fv.grid.slot_total * 4));
     }
@@ -863,6 +872,26 @@ int rdr_set_shade_rows(rdr_renderer* r, uint32_t row_lo, uint32_t row_hi) {
     RDR_CHECK(r, "rdr_set_shade_rows: renderer is null");
     RDR_CHECK(row_lo <= row_hi, "rdr_set_shade_rows: lo > hi");
     r->row_lo = row_lo; r->row_hi = row_hi;
+    r->band_world = 1; r->band_rank = 0;
+    return 0;
+}
+
+int rdr_set_partition_interleaved(rdr_renderer* r, uint32_t chunk, uint32_t rank, uint32_t world) {
+    RDR_CHECK(r, "rdr_set_partition_interleaved: renderer is null");
+    RDR_CHECK(world >= 1 && rank < world, "rdr_set_partition_interleaved: rank must be below world");
+    RDR_CHECK(chunk >= 64 && chunk % 64 == 0 && chunk <= (1u << 20), "rdr_set_partition_interleaved: chunk must be a multiple of 64, at most 2^20");
+    r->part_chunk = chunk; r->part_rank = rank; r->part_world = world;
+    return 0;
+}
+
+int rdr_set_shade_bands(rdr_renderer* r, uint32_t band, uint32_t rank, uint32_t world) {
+    RDR_CHECK(r, "rdr_set_shade_bands: renderer is null");
+    RDR_CHECK(world >= 1 && rank < world, "rdr_set_shade_bands: rank must be below world");
+    RDR_CHECK(band >= 32 && band <= 16384 && (band & (band - 1)) == 0, "rdr_set_shade_bands: band must be a power of two between 32 and 16384");
+    uint32_t shift = 5;
+    while ((1u << shift) < band) ++shift;
+    r->band_shift = shift; r->band_rank = rank; r->band_world = world;
+    r->row_lo = 0; r->row_hi = 0xFFFFFFFFu;
     return 0;
 }
 
@@ -937,7 +966,7 @@ int rdr_composite_exchange(rdr_renderer* r) {
     RDR_CHECK(r->frame_has_tile_flags, "rdr_composite_exchange: the visibility buffer was rendered before rdr_composite_connect; render it again");
     RDR_HIP(hipSetDevice(r->device));
     if (rdr_composite_check(r->composite, "rdr_composite_exchange")) return 1;
-    return rdr_composite_launch_exchange(r->composite, std::min(r->row_lo, r->height), std::min(r->row_hi, r->height), r->stream);
+    return rdr_composite_launch_exchange(r->composite, shaded_rows(r), r->stream);
 }
 
 int rdr_composite_gather(rdr_renderer* r) {
@@ -945,7 +974,7 @@ int rdr_composite_gather(rdr_renderer* r) {
     RDR_CHECK(r->shaded, "rdr_composite_gather: nothing shaded yet");
     RDR_HIP(hipSetDevice(r->device));
     if (rdr_composite_check(r->composite, "rdr_composite_gather")) return 1;
-    return rdr_composite_launch_gather(r->composite, std::min(r->row_lo, r->height), std::min(r->row_hi, r->height), r->cfg.skybox != 0, r->stream);
+    return rdr_composite_launch_gather(r->composite, shaded_rows(r), r->cfg.skybox != 0, r->stream);
 }
 
 int rdr_composite_disconnect(rdr_renderer* r) {

@@ -64,13 +64,20 @@ __global__ void k_signal_wait(PeerTable peers, const uint32_t* ctrl, uint32_t ra
 // the ranks that touched it only.  On the bench field at eight ranks that is about a tenth of the strips.
 struct TileGrid {
     uint32_t width, height;   // of the frame
-    uint32_t row_lo, row_hi;  // this rank's strip
+    uint32_t row_lo, row_hi;  // this rank's strip (the whole frame when its rows are bands)
     uint32_t tiles_x;         // tiles per row of the frame
-    uint32_t tile_row0;       // first tile row that overlaps the strip
+    uint32_t tile_row0;       // strip: first tile row that overlaps it
+    uint32_t band_tiles_shift, band_rank, band_world; // bands (band_world > 1): log2 of the tile rows per band, and which bands
 };
 
-__device__ __forceinline__ bool tile_rect(const TileGrid& g, uint32_t& x0, uint32_t& x1, uint32_t& y0, uint32_t& y1) {
-    const uint32_t ty = g.tile_row0 + blockIdx.y;
+// The tile row a workgroup row of the grid stands for: the strip's tile rows in order, or the rank's bands' tile rows.
+__device__ __forceinline__ uint32_t tile_row(const TileGrid& g) {
+    if (g.band_world <= 1u) return g.tile_row0 + blockIdx.y;
+    const uint32_t band = blockIdx.y >> g.band_tiles_shift;
+    return ((band * g.band_world + g.band_rank) << g.band_tiles_shift) | (blockIdx.y & ((1u << g.band_tiles_shift) - 1u));
+}
+
+__device__ __forceinline__ bool tile_rect(const TileGrid& g, uint32_t ty, uint32_t& x0, uint32_t& x1, uint32_t& y0, uint32_t& y1) {
     x0 = blockIdx.x * kTouchTile; x1 = min(x0 + kTouchTile, g.width);
     y0 = max(ty * kTouchTile, g.row_lo); y1 = min(ty * kTouchTile + kTouchTile, g.row_hi);
     return x0 < x1 && y0 < y1;
@@ -82,7 +89,9 @@ __device__ __forceinline__ bool tile_rect(const TileGrid& g, uint32_t& x0, uint3
 __global__ __launch_bounds__(256) void k_composite_tiles(PeerTable peers, uint32_t rank, uint32_t world, TileGrid g, uint32_t* union_now,
                                                          uint32_t use_flags) {
     __shared__ uint32_t s_mask;
-    const uint32_t tile = (g.tile_row0 + blockIdx.y) * g.tiles_x + blockIdx.x;
+    const uint32_t ty = tile_row(g);
+    if (ty * kTouchTile >= g.height) return; // the whole workgroup
+    const uint32_t tile = ty * g.tiles_x + blockIdx.x;
     if (threadIdx.x < 64) {
         uint32_t f = 0;
         if (threadIdx.x < world) f = use_flags ? peers.touched[threadIdx.x][tile] : 1u;
@@ -95,7 +104,7 @@ __global__ __launch_bounds__(256) void k_composite_tiles(PeerTable peers, uint32
     __syncthreads();
     const uint32_t others = __builtin_amdgcn_readfirstlane(s_mask) & ~(1u << rank);
     uint32_t x0, x1, y0, y1;
-    if (!others || !tile_rect(g, x0, x1, y0, y1)) return; // nobody else drew here: this rank's keys are the result
+    if (!others || !tile_rect(g, ty, x0, x1, y0, y1)) return; // nobody else drew here: this rank's keys are the result
     if ((g.width & 1u) == 0u) {
         // even width: a tile row starts on a 16-byte boundary and holds whole pairs
         const uint32_t per_row = (x1 - x0) / 2u, n = per_row * (y1 - y0);
@@ -139,12 +148,14 @@ __global__ __launch_bounds__(256) void k_composite_tiles(PeerTable peers, uint32
 // colour) writes all of them.
 __global__ __launch_bounds__(256) void k_push_tiles(PeerTable peers, uint32_t rank, uint32_t world, TileGrid g, const uint32_t* union_now,
                                                     uint32_t* union_prev, uint32_t every_tile) {
-    const uint32_t tile = (g.tile_row0 + blockIdx.y) * g.tiles_x + blockIdx.x;
+    const uint32_t ty = tile_row(g);
+    if (ty * kTouchTile >= g.height) return; // the whole workgroup
+    const uint32_t tile = ty * g.tiles_x + blockIdx.x;
     const uint32_t now = union_now[tile], need = every_tile | now | union_prev[tile];
     __syncthreads(); // every thread has read union_prev before it changes
     if (threadIdx.x == 0) union_prev[tile] = now;
     uint32_t x0, x1, y0, y1;
-    if (!need || !tile_rect(g, x0, x1, y0, y1)) return;
+    if (!need || !tile_rect(g, ty, x0, x1, y0, y1)) return;
     if ((g.width & 3u) == 0u) {
         const uint32_t per_row = (x1 - x0) / 4u, n = per_row * (y1 - y0);
         for (uint32_t i = threadIdx.x; i < n; i += 256u) {
@@ -183,17 +194,34 @@ struct rdr_composite_state {
     uint32_t width = 0, height = 0;
     uint32_t* union_now = nullptr;
     uint32_t* union_prev = nullptr;
-    uint32_t pushed_lo = 0xFFFFFFFFu, pushed_hi = 0xFFFFFFFFu; // the strip union_prev describes
+    RowSet pushed{0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0}; // the rows union_prev describes
     bool use_flags = true;
 };
 
-static TileGrid tile_grid(const rdr_composite_state* c, uint32_t row_lo, uint32_t row_hi, dim3& grid) {
-    TileGrid g;
-    g.width = c->width; g.height = c->height; g.row_lo = row_lo; g.row_hi = row_hi;
+static bool same_rows(const RowSet& a, const RowSet& b) {
+    return a.row_lo == b.row_lo && a.row_hi == b.row_hi && a.band_shift == b.band_shift && a.band_rank == b.band_rank && a.band_world == b.band_world;
+}
+
+// Grid over the tiles of the rank's rows; false when it has none.
+static bool tile_grid(const rdr_composite_state* c, const RowSet& rows, TileGrid& g, dim3& grid) {
+    g.width = c->width; g.height = c->height;
     g.tiles_x = (c->width + kTouchTile - 1) / kTouchTile;
-    g.tile_row0 = row_lo / kTouchTile;
-    grid = dim3(g.tiles_x, (row_hi + kTouchTile - 1) / kTouchTile - g.tile_row0);
-    return g;
+    g.band_rank = rows.band_rank; g.band_world = rows.band_world;
+    g.band_tiles_shift = 0; g.tile_row0 = 0;
+    uint32_t tile_rows = 0;
+    if (rows.band_world > 1u) {
+        g.row_lo = 0; g.row_hi = c->height;
+        uint32_t band_tiles = (1u << rows.band_shift) / kTouchTile; // a power of two (rdr_set_shade_bands)
+        while ((1u << g.band_tiles_shift) < band_tiles) ++g.band_tiles_shift;
+        tile_rows = (rdr_band_rows(c->height, rows.band_shift, rows.band_rank, rows.band_world) + kTouchTile - 1) / kTouchTile;
+    } else {
+        g.row_lo = rows.row_lo; g.row_hi = rows.row_hi;
+        if (rows.row_hi <= rows.row_lo) return false;
+        g.tile_row0 = rows.row_lo / kTouchTile;
+        tile_rows = (rows.row_hi + kTouchTile - 1) / kTouchTile - g.tile_row0;
+    }
+    grid = dim3(g.tiles_x, tile_rows);
+    return tile_rows != 0;
 }
 
 int rdr_composite_create(rdr_composite_state** out) {
@@ -261,7 +289,7 @@ int rdr_composite_open(rdr_composite_state* c, uint32_t rank, uint32_t world, co
     RDR_HIP(hipMalloc(reinterpret_cast<void**>(&c->union_now), words * 4));
     RDR_HIP(hipMalloc(reinterpret_cast<void**>(&c->union_prev), words * 4));
     RDR_HIP(hipMemset(c->union_now, 0, words * 4));
-    c->pushed_lo = c->pushed_hi = 0xFFFFFFFFu; // nothing is known about the peers' images yet
+    c->pushed = RowSet{0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0}; // nothing is known about the peers' images yet
     if (const char* e = std::getenv("RDR_COMPOSITE_TILE_FLAGS")) c->use_flags = std::atoi(e) != 0; // measurement hook: 0 = every tile
     for (uint32_t p = 0; p < world; ++p) {
         if (p == rank) {
@@ -299,34 +327,33 @@ int rdr_composite_check(rdr_composite_state* c, const char* who) {
     return 0;
 }
 
-// keys of rows [row_lo, row_hi): wait for every rank's keys, take the minimum into this rank's buffer
-int rdr_composite_launch_exchange(rdr_composite_state* c, uint32_t row_lo, uint32_t row_hi, hipStream_t stream) {
+// keys of the rank's rows: wait for every rank's keys, take the minimum into this rank's buffer
+int rdr_composite_launch_exchange(rdr_composite_state* c, const RowSet& rows, hipStream_t stream) {
     RDR_CHECK(c->connected, "rdr_composite_exchange: not connected");
     c->frame++;
     const uint32_t base = 2u * c->frame;
     hipLaunchKernelGGL(k_signal_wait, dim3(1), dim3(64), 0, stream, c->peers, c->ctrl, c->rank, c->world, base + 1u, c->timed_out_dev);
-    if (row_hi > row_lo) {
-        dim3 grid;
-        const TileGrid g = tile_grid(c, row_lo, row_hi, grid);
+    dim3 grid;
+    TileGrid g;
+    if (tile_grid(c, rows, g, grid))
         hipLaunchKernelGGL(k_composite_tiles, grid, dim3(256), 0, stream, c->peers, c->rank, c->world, g, c->union_now, c->use_flags ? 1u : 0u);
-    }
     RDR_HIP(hipGetLastError());
     return 0;
 }
 
-// colour rows [row_lo, row_hi) into every peer's image, then wait until every peer's rows are here
-int rdr_composite_launch_gather(rdr_composite_state* c, uint32_t row_lo, uint32_t row_hi, bool every_tile, hipStream_t stream) {
+// the rank's colour rows into every peer's image, then wait until every peer's rows are here
+int rdr_composite_launch_gather(rdr_composite_state* c, const RowSet& rows, bool every_tile, hipStream_t stream) {
     RDR_CHECK(c->connected, "rdr_composite_gather: not connected");
     RDR_CHECK(c->frame > 0, "rdr_composite_gather: no exchange has run for this frame");
     const uint32_t base = 2u * c->frame;
-    if (row_hi > row_lo) {
-        if (row_lo != c->pushed_lo || row_hi != c->pushed_hi) {
-            // a new strip: what the peers' images hold in it is unknown, so every tile counts as written before
+    dim3 grid;
+    TileGrid g;
+    if (tile_grid(c, rows, g, grid)) {
+        if (!same_rows(rows, c->pushed)) {
+            // other rows than the last time: what the peers' images hold in them is unknown, so every tile counts as written before
             RDR_HIP(hipMemsetAsync(c->union_prev, 0x01, (size_t)rdr_touched_words(c->width, c->height) * 4, stream));
-            c->pushed_lo = row_lo; c->pushed_hi = row_hi;
+            c->pushed = rows;
         }
-        dim3 grid;
-        const TileGrid g = tile_grid(c, row_lo, row_hi, grid);
         hipLaunchKernelGGL(k_push_tiles, grid, dim3(256), 0, stream, c->peers, c->rank, c->world, g, c->union_now, c->union_prev,
                            (every_tile || !c->use_flags) ? 1u : 0u);
     }

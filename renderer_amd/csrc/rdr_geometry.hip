@@ -79,6 +79,19 @@ RDR_DEV bool sphere_occluded(const FrameView& fv, vec3 c, float r) {
     return nearest < __uint_as_float(far_bits);
 }
 
+// The meshlets [k_lo, k_hi) of draw `di` that belong to this renderer's sort-last share, as spans f(lo, hi) of at
+// most one chunk each: everything, or (FrameView::part_world > 1) the chunks j with (j + di) % world == rank.
+template <typename F>
+RDR_DEV void own_spans(const FrameView& fv, uint32_t di, uint32_t k_lo, uint32_t k_hi, F f) {
+    if (fv.part_world <= 1u) {
+        if (k_hi > k_lo) f(k_lo, k_hi);
+        return;
+    }
+    uint32_t j = k_lo / fv.part_chunk;
+    j += (fv.part_rank + fv.part_world - (j + di) % fv.part_world) % fv.part_world; // the first own chunk at or after j
+    for (; j * fv.part_chunk < k_hi; j += fv.part_world) f(max(k_lo, j * fv.part_chunk), min(k_hi, (j + 1u) * fv.part_chunk));
+}
+
 // ------------------------------------------------------------------------------
 // Draw cull.  PHASE: single pass; early (draws visible last frame only, opaque only);
 // late (every draw, opaque ones tested against the pyramid; masked draws are emitted
@@ -132,7 +145,7 @@ __global__ __launch_bounds__(256) void k_draw_cull(SceneView sv, FrameView fv) {
             if (hi > lo) {
                 k_lo = lo - vis_off;
                 k_hi = hi - vis_off;
-                ncmd = (k_hi - k_lo + 63u) / 64u;
+                own_spans(fv, di, k_lo, k_hi, [&](uint32_t a, uint32_t b) { ncmd += (b - a + 63u) / 64u; });
             }
             emitted = true;
         }
@@ -154,18 +167,21 @@ __global__ __launch_bounds__(256) void k_draw_cull(SceneView sv, FrameView fv) {
     if (lane == 0 && total) base = atomicAdd(&fv.counters->cmd_count, total);
     base = __shfl(base, 0, 64);
     uint32_t slot = base + incl - ncmd;
-    for (uint32_t i = 0; i < ncmd; ++i, ++slot) {
-        if (slot >= fv.command_capacity) break;
-        CullCommand cmd;
-        cmd.draw_id = di;
-        cmd.meshlet_first = lod_meshlet_offset + k_lo + i * 64u;
-        cmd.count = min(64u, k_hi - k_lo - i * 64u);
-        cmd.instance_first = vis_off + k_lo + i * 64u;
-        cmd.max_scale = max_scale;
-        cmd.late_draw_visibility = was_visible;
-        cmd._pad[0] = cmd._pad[1] = 0;
-        fv.commands[slot] = cmd;
-    }
+    if (ncmd)
+        own_spans(fv, di, k_lo, k_hi, [&](uint32_t a, uint32_t b) {
+            for (uint32_t k = a; k < b; k += 64u, ++slot) {
+                if (slot >= fv.command_capacity) return;
+                CullCommand cmd;
+                cmd.draw_id = di;
+                cmd.meshlet_first = lod_meshlet_offset + k;
+                cmd.count = min(64u, b - k);
+                cmd.instance_first = vis_off + k;
+                cmd.max_scale = max_scale;
+                cmd.late_draw_visibility = was_visible;
+                cmd._pad[0] = cmd._pad[1] = 0;
+                fv.commands[slot] = cmd;
+            }
+        });
     if (fv.collect_stats) {
         __shared__ uint32_t wg_emitted[4];
         const uint32_t n = wave_sum(emitted ? 1u : 0u);

@@ -346,7 +346,13 @@ struct FrameView {
     uint32_t* tile_count_next;
     uint32_t width, height;
     uint32_t part_lo, part_hi;
+    // Interleaved sort-last share on top of the range (part_world > 1): chunk j of draw d (chunks of part_chunk
+    // consecutive meshlets of the draw's level of detail) belongs to rank (j + d) % part_world.
+    uint32_t part_chunk, part_rank, part_world;
+    // The rows this renderer shades, as `shade_rows` virtual rows: a contiguous range (band_world <= 1: virtual
+    // row v is row row_lo + v) or every band_world-th band of (1 << band_shift) rows starting with band band_rank.
     uint32_t row_lo, row_hi;
+    uint32_t band_shift, band_rank, band_world, shade_rows;
     uint32_t command_capacity, visible_capacity, deferred_capacity;
     uint32_t collect_stats;
     uint32_t* pixel_list; // the covered pixels of the shaded rows (k_classify), as y << 16 | x
@@ -411,6 +417,20 @@ struct FrameView {
     GridPlan grid;
 };
 
+// Frame row of the renderer's v-th shaded row (FrameView::shade_rows of them).
+__host__ __device__ inline uint32_t rdr_shade_row(const FrameView& fv, uint32_t v) {
+    if (fv.band_world <= 1u) return fv.row_lo + v;
+    const uint32_t band = v >> fv.band_shift;
+    return (((band * fv.band_world + fv.band_rank) << fv.band_shift) | (v & ((1u << fv.band_shift) - 1u)));
+}
+// Rows of a frame of `height` rows that belong to rank `rank` of `world` when bands of (1 << shift) rows are dealt round-robin.
+inline uint32_t rdr_band_rows(uint32_t height, uint32_t shift, uint32_t rank, uint32_t world) {
+    const uint32_t band = 1u << shift, cycle = band * world;
+    const uint32_t full = height / cycle, rest = height % cycle;
+    const uint32_t lo = rank * band;
+    return full * band + (rest > lo ? (rest - lo < band ? rest - lo : band) : 0u);
+}
+
 // ---- host BVH builder (rdr_bvh.cpp) -----------------------------------------
 struct HostBvh {
     std::vector<BvhWide> blas_pairs, tlas_pairs;
@@ -455,8 +475,13 @@ int rdr_composite_open(rdr_composite_state* c, uint32_t rank, uint32_t world, co
 bool rdr_composite_connected(const rdr_composite_state* c);
 int rdr_composite_check(rdr_composite_state* c, const char* who);
 bool rdr_composite_timed_out(const rdr_composite_state* c); // a bounded wait gave up (not cleared by asking)
-int rdr_composite_launch_exchange(rdr_composite_state* c, uint32_t row_lo, uint32_t row_hi, hipStream_t stream);
-int rdr_composite_launch_gather(rdr_composite_state* c, uint32_t row_lo, uint32_t row_hi, bool every_tile, hipStream_t stream);
+// The rows a rank composites and pushes: [row_lo, row_hi), or (band_world > 1) its bands of (1 << band_shift) rows.
+struct RowSet {
+    uint32_t row_lo, row_hi;
+    uint32_t band_shift, band_rank, band_world;
+};
+int rdr_composite_launch_exchange(rdr_composite_state* c, const RowSet& rows, hipStream_t stream);
+int rdr_composite_launch_gather(rdr_composite_state* c, const RowSet& rows, bool every_tile, hipStream_t stream);
 // Edge of the tiles of FrameView::touched, and the words to reserve for them behind a width x height visibility buffer.
 constexpr uint32_t kTouchTile = 32;
 inline uint32_t rdr_touched_words(uint32_t width, uint32_t height) {

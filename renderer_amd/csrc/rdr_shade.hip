@@ -319,8 +319,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // ray (implicit LOD taken as 0), sRGB-encoded by the store; alpha is stored as is.
 __global__ __launch_bounds__(256) void k_skybox(SceneView sv, FrameView fv) {
     const uint32_t ix = blockIdx.x * 64u + (threadIdx.x & 63u);
-    const uint32_t iy = fv.row_lo + blockIdx.y * 4u + (threadIdx.x >> 6);
-    if (ix >= fv.width || iy >= fv.row_hi) return;
+    const uint32_t vrow = blockIdx.y * 4u + (threadIdx.x >> 6); // of the rows this renderer shades
+    if (ix >= fv.width || vrow >= fv.shade_rows) return;
+    const uint32_t iy = rdr_shade_row(fv, vrow);
     const size_t pi = (size_t)iy * fv.width + ix;
     if (fv.vis[pi] != RDR_VIS_CLEAR) return;
     const rdr_ubo& u = fv.ubo;
@@ -338,12 +339,12 @@ __global__ __launch_bounds__(256) void k_skybox(SceneView sv, FrameView fv) {
 } // namespace
 
 int rdr_launch_shade(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev) {
-    if (fv.row_hi <= fv.row_lo) return 0;
+    if (fv.shade_rows == 0u) return 0;
     if (rdr_launch_shadow(sv, fv, stream, ev)) return 1;
-    const uint32_t list_blocks = (uint32_t)(((size_t)(fv.row_hi - fv.row_lo) * fv.width + 255u) / 256u);
+    const uint32_t list_blocks = (uint32_t)(((size_t)fv.shade_rows * fv.width + 255u) / 256u);
     hipLaunchKernelGGL(k_shade, dim3(list_blocks), dim3(256), 0, stream, sv, fv);
     if (fv.skybox)
-        hipLaunchKernelGGL(k_skybox, dim3((fv.width + 63u) / 64u, (fv.row_hi - fv.row_lo + 3u) / 4u), dim3(256), 0, stream, sv, fv);
+        hipLaunchKernelGGL(k_skybox, dim3((fv.width + 63u) / 64u, (fv.shade_rows + 3u) / 4u), dim3(256), 0, stream, sv, fv);
     if (ev) RDR_HIP(hipEventRecord(ev[9], stream));
     RDR_HIP(hipGetLastError());
     return 0;

@@ -459,15 +459,16 @@ __global__ __launch_bounds__(1024) void k_classify(FrameView fv) {
     __shared__ uint32_t wg_base;
     const uint32_t lane = threadIdx.x & 63u, wave = (threadIdx.x >> 6) & 3u, quad = threadIdx.x >> 8;
     const uint32_t x0 = blockIdx.x * kClassifyRegion + (quad & 1u) * 64 + (wave & 1u) * 8 + (lane & 7u);
-    const uint32_t y0 = fv.row_lo + blockIdx.y * kClassifyRegion + (quad >> 1) * 64 + (wave >> 1) * 8 + (lane >> 3);
+    const uint32_t v0 = blockIdx.y * kClassifyRegion + (quad >> 1) * 64 + (wave >> 1) * 8 + (lane >> 3); // of the rows this renderer shades
     uint32_t covered_bits = 0;
     uint32_t ids[16]; // low words of the covered pixels' keys, for the list
     uint32_t* color = reinterpret_cast<uint32_t*>(fv.color);
 #pragma unroll
     for (uint32_t b = 0; b < 16; ++b) {
-        const uint32_t ix = x0 + (b & 3u) * 16, iy = y0 + (b >> 2) * 16;
+        const uint32_t ix = x0 + (b & 3u) * 16, vy = v0 + (b >> 2) * 16;
         bool covered = false;
-        if (ix < fv.width && iy < fv.row_hi) {
+        if (ix < fv.width && vy < fv.shade_rows) {
+            const uint32_t iy = rdr_shade_row(fv, vy);
             const uint32_t pi = iy * fv.width + ix;
             const unsigned long long key = fv.vis[pi];
             covered = key != RDR_VIS_CLEAR;
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(1024) void k_classify(FrameView fv) {
         const bool covered = (covered_bits >> b) & 1u;
         const unsigned long long m = __ballot(covered);
         if (covered) {
-            const uint32_t ix = x0 + (b & 3u) * 16, iy = y0 + (b >> 2) * 16;
+            const uint32_t ix = x0 + (b & 3u) * 16, iy = rdr_shade_row(fv, v0 + (b >> 2) * 16);
             const uint32_t at = base + wave_count[quad * 64 + b * 4 + wave] + ballot_rank(m);
             fv.pixel_list[at] = (iy << 16) | ix;
             fv.pixel_key[at] = ids[b];
@@ -611,11 +612,11 @@ int rdr_launch_sun_candidates(const SceneView& sv, const FrameView& fv, hipStrea
 }
 
 int rdr_launch_shadow(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev) {
-    if (fv.row_hi <= fv.row_lo) return 0;
-    const dim3 tiles((fv.width + kClassifyRegion - 1u) / kClassifyRegion, (fv.row_hi - fv.row_lo + kClassifyRegion - 1u) / kClassifyRegion);
+    if (fv.shade_rows == 0u) return 0;
+    const dim3 tiles((fv.width + kClassifyRegion - 1u) / kClassifyRegion, (fv.shade_rows + kClassifyRegion - 1u) / kClassifyRegion);
     // the list passes are launched for the worst case (every pixel covered); workgroups
     // beyond the list's length exit on their first instruction
-    const uint32_t list_blocks = (uint32_t)(((size_t)(fv.row_hi - fv.row_lo) * fv.width + 255u) / 256u);
+    const uint32_t list_blocks = (uint32_t)(((size_t)fv.shade_rows * fv.width + 255u) / 256u);
     if (ev) RDR_HIP(hipEventRecord(ev[6], stream));
     // pixel_count, shadow_overflow: zeroed by the geometry pass's clear; only a second shading pass over the
     // same visibility buffer has to reset them (a memset between kernels is a 4 us kernel of its own)

@@ -9,7 +9,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from renderer_amd import Renderer, RendererConfig, synth  # noqa: E402
-from renderer_amd.distributed import instance_range, row_range  # noqa: E402
+from renderer_amd.distributed import band_row_index, instance_range, row_range  # noqa: E402
 from renderer_amd.scene import Camera  # noqa: E402
 
 W, H = (int(v) for v in os.environ.get("P2P_SIZE", "256x144").split("x"))
@@ -36,9 +36,15 @@ def main():
     conf = RendererConfig(cull_enabled=os.environ.get("P2P_OCCLUSION") == "1", skybox=os.environ.get("P2P_SKYBOX") == "1")
     r = Renderer(W, H, conf, device=device)
     r.set_scene(scene)
-    r.set_partition(*instance_range(scene.meshlet_visibility_count, rank, world))
-    lo, hi = row_range(H, rank, world)
-    r.set_shade_rows(lo, hi)
+    if os.environ.get("P2P_SPLIT", "interleaved") == "interleaved":  # chunks of meshlets and bands of rows dealt round-robin
+        r.set_partition_interleaved(64, rank, world)
+        r.set_shade_bands(32, rank, world)
+        mine = band_row_index(H, 32, rank, world).numpy()
+    else:
+        r.set_partition(*instance_range(scene.meshlet_visibility_count, rank, world))
+        lo, hi = row_range(H, rank, world)
+        r.set_shade_rows(lo, hi)
+        mine = np.arange(lo, hi)
     publish(os.path.join(d, f"handle_{rank}.bin"), r.composite_export())
     names = [os.path.join(d, f"handle_{k}.bin") for k in range(world)]
     wait_for(names)
@@ -97,8 +103,8 @@ def main():
         whole.render(cam)
         vis, color = whole.read_visbuffer_u64(), whole.read_color()
         gv, gc = frames[k]
-        if not np.array_equal(gv[lo:hi], vis[lo:hi]):
-            print(f"rank {rank} frame {k}: {int((gv[lo:hi] != vis[lo:hi]).sum())} composited keys differ", flush=True)
+        if not np.array_equal(gv[mine], vis[mine]):
+            print(f"rank {rank} frame {k}: {int((gv[mine] != vis[mine]).sum())} composited keys differ", flush=True)
             ok = False
         if not np.array_equal(gc, color):
             print(f"rank {rank} frame {k}: {int((gc != color).any(axis=2).sum())} pixels of the gathered image differ", flush=True)

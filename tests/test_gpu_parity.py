@@ -323,6 +323,81 @@ def test_partitions_composite_to_full_frame(oracle):
     assert np.array_equal(o.render_visbuffer(), parts[1])
 
 
+@pytest.mark.parametrize("world,chunk", [(2, 64), (3, 64), (8, 64), (5, 128)])
+def test_interleaved_partitions_composite_to_full_frame(oracle, world, chunk):
+    """Chunks of every draw's meshlets dealt round-robin (rdr_set_partition_interleaved): each rank's buffer is
+    the oracle's for the same share, the shares' work counters add up to the frame's, and the minimum over the
+    ranks is the full frame; with level-of-detail selection on, chunks are counted within the selected level."""
+    sc = synth.make_field(60, 4, lods=3, alpha_fraction=0.3)
+    w, h = 320, 180
+    conf = RendererConfig(lod_enabled=True, cull_enabled=False)
+    g = Renderer(w, h, conf)
+    g.set_scene(sc)
+    g.render_visbuffer()
+    full = g.read_visbuffer_u64().copy()
+    whole = g.stats()
+    o = oracle.OracleRenderer(w, h, conf)
+    o.set_scene(sc)
+    acc = np.full_like(full, abi.VIS_CLEAR)
+    sums = dict.fromkeys(STAT_KEYS[1:], 0)
+    for rank in range(world):
+        g.set_partition_interleaved(chunk, rank, world)
+        g.render_visbuffer()
+        part = g.read_visbuffer_u64()
+        if rank in (0, world - 1):
+            o.set_partition_interleaved(chunk, rank, world)
+            assert np.array_equal(o.render_visbuffer(), part)
+        st = g.stats()
+        for k in sums:
+            sums[k] += st[k]
+        acc = np.minimum(acc, part)
+    assert np.array_equal(acc, full)
+    assert sums == {k: whole[k] for k in sums}
+    # the range still applies on top of the interleaving
+    n = sc.meshlet_visibility_count
+    g.set_partition(n // 3, n)
+    g.set_partition_interleaved(chunk, 0, world)
+    g.render_visbuffer()
+    o.set_partition(n // 3, n)
+    o.set_partition_interleaved(chunk, 0, world)
+    assert np.array_equal(o.render_visbuffer(), g.read_visbuffer_u64())
+    with pytest.raises(RendererError, match="multiple of 64"):
+        g.set_partition_interleaved(48, 0, 2)
+    with pytest.raises(RendererError, match="below world"):
+        g.set_partition_interleaved(64, 2, 2)
+    g.close()
+
+
+@pytest.mark.parametrize("world,band,size", [(2, 32, (320, 180)), (3, 32, (333, 187)), (8, 32, (256, 300)), (2, 64, (320, 180))])
+def test_shade_bands_compose_to_the_full_image(world, band, size):
+    """Bands of rows dealt round-robin (rdr_set_shade_bands): a rank shades exactly its rows, and the ranks'
+    rows together are the full image (skybox pixels included)."""
+    sc = synth.make_field(40, 3, lods=1, with_env=True)
+    w, h = size
+    g = Renderer(w, h, RendererConfig(cull_enabled=False, skybox=True))
+    g.set_scene(sc)
+    g.render()
+    full = g.read_color().copy()
+    covered_all = g.stats()["pixels_covered"]
+    acc = np.zeros_like(full)
+    covered_sum = 0
+    for rank in range(world):
+        g.set_shade_bands(band, rank, world)
+        g.render()
+        img = g.read_color()
+        mine = ((np.arange(h) // band) % world) == rank
+        acc[mine] = img[mine]
+        covered_sum += g.stats()["pixels_covered"]
+    assert np.array_equal(acc, full)
+    assert covered_sum == covered_all
+    g.set_shade_rows(0, h)  # back to a plain range
+    g.render()
+    assert np.array_equal(g.read_color(), full)
+    with pytest.raises(RendererError, match="power of two"):
+        g.set_shade_bands(48, 0, 2)
+    g.close()
+
+
 def test_update_transforms(oracle):
     sc = synth.make_field(30, 2)
     sc.camera = Camera((0.0, 4.0, -14.0), (0.0, 0.25, -1.0))
@@ -377,24 +452,26 @@ def test_errors():
 
 def test_full_size_properties():
     """At the benchmark's size the oracle is too slow to run in a test; check size-independent
-    properties instead: sort-last partitions min-compose to the full frame, every key decodes to
-    a valid (draw, meshlet, triangle), shading covers exactly the keyed pixels."""
-    sc = synth.make_field(1250, 5, with_env=True)
+    properties instead, on the scene the benchmark times (meshlets from the library's mesh preparation):
+    sort-last partitions min-compose to the full frame (contiguous thirds and interleaved eighths), every key
+    decodes to a valid (draw, meshlet, triangle), shading covers exactly the keyed pixels, a second frame repeats
+    the first."""
+    sc = synth.make_field(1250, 5, lods=1, with_env=True, prepared=True)
     w, h = 3840, 2160
-    g = Renderer(w, h)
+    g = Renderer(w, h, RendererConfig(lod_enabled=False, cull_enabled=False))
     g.set_scene(sc)
     g.render()
-    full = g.read_visbuffer_u64()
+    assert g.frame_status() == 0
+    full = g.read_visbuffer_u64().copy()
     st = g.stats()
     assert st["triangles_submitted"] == st["draws_visible"] * 20480 <= sc.triangle_count() == 1250 * 20480
     cov = covered(full)
     assert st["pixels_covered"] == int(cov.sum()) > 0
-    xy = g.read_visbuffer()
-    draw, meshlet, tri = xy[..., 1][cov], xy[..., 0][cov] >> 8, xy[..., 0][cov] & 0xFF
-    assert draw.max() < len(sc.mesh_draws) and meshlet.max() < len(sc.meshlets)
-    assert (tri < sc.meshlets["triangle_count"][meshlet]).all()
-    col = g.read_color()
+    _valid_keys(sc, g, cov)
+    col = g.read_color().copy()
     assert (col[..., 3][cov] == 255).all() and (col[~cov] == 0).all()
+    g.render()
+    assert np.array_equal(g.read_visbuffer_u64(), full) and np.array_equal(g.read_color(), col)
     n = sc.meshlet_visibility_count
     acc = np.full_like(full, abi.VIS_CLEAR)
     for k in range(3):
@@ -402,6 +479,67 @@ def test_full_size_properties():
         g.render_visbuffer()
         acc = np.minimum(acc, g.read_visbuffer_u64())
     assert np.array_equal(acc, full)
+    g.set_partition(0, n)
+    acc = np.full_like(full, abi.VIS_CLEAR)
+    for k in range(8):
+        g.set_partition_interleaved(64, k, 8)
+        g.render_visbuffer()
+        acc = np.minimum(acc, g.read_visbuffer_u64())
+    assert np.array_equal(acc, full)
+    g.close()
+
+
+SECONDARY_FIELDS = {
+    # the benchmark's secondary field series, by the same constructors and configurations
+    "alpha": (dict(lods=1, alpha_fraction=0.5), dict(lod_enabled=False, cull_enabled=False)),
+    "lod": (dict(lods=8), dict(lod_enabled=True, cull_enabled=False)),
+    "occlusion": (dict(lods=1), dict(lod_enabled=False, cull_enabled=True)),
+}
+
+
+@pytest.mark.parametrize("series", sorted(SECONDARY_FIELDS))
+def test_secondary_field_series_4k_properties(series):
+    """The other field workloads the benchmark times, at its size: complete frame, valid keys, shading covers
+    exactly the keyed pixels, a second frame repeats the first, interleaved partitions min-compose to the full
+    frame, and two-phase occlusion culling changes neither the keys nor the image."""
+    scene_kw, conf_kw = SECONDARY_FIELDS[series]
+    sc = synth.make_field(1250, 5, with_env=True, prepared=True, **scene_kw)
+    w, h = 3840, 2160
+    g = Renderer(w, h, RendererConfig(**conf_kw))
+    g.set_scene(sc)
+    for _ in range(2 if conf_kw["cull_enabled"] else 1):  # second frame: the early phase has something to draw
+        g.render()
+    assert g.frame_status() == 0
+    full = g.read_visbuffer_u64().copy()
+    col = g.read_color().copy()
+    st = g.stats()
+    cov = covered(full)
+    assert st["pixels_covered"] == int(cov.sum()) > w * h // 8
+    _valid_keys(sc, g, cov)
+    assert (col[..., 3][cov] == 255).all() and (col[~cov] == 0).all()
+    if series == "lod":
+        assert 0 < st["triangles_submitted"] < sc.triangle_count()
+    g.render()
+    assert g.frame_status() == 0
+    assert np.array_equal(g.read_visbuffer_u64(), full) and np.array_equal(g.read_color(), col)
+    acc = np.full_like(full, abi.VIS_CLEAR)
+    for k in range(4):
+        g.set_partition_interleaved(64, k, 4)
+        for _ in range(2 if conf_kw["cull_enabled"] else 1):
+            g.render_visbuffer()
+        assert g.frame_status() == 0
+        acc = np.minimum(acc, g.read_visbuffer_u64())
+    assert np.array_equal(acc, full)
+    g.close()
+    # the other setting of the occlusion switch: bit for bit the same keys and image
+    other = dict(conf_kw, cull_enabled=not conf_kw["cull_enabled"])
+    c = Renderer(w, h, RendererConfig(**other))
+    c.set_scene(sc)
+    for _ in range(3):
+        c.render()
+    assert c.frame_status() == 0
+    assert np.array_equal(c.read_visbuffer_u64(), full) and np.array_equal(c.read_color(), col)
+    c.close()
 
 
 def _valid_keys(sc, g, cov):
