@@ -24,6 +24,7 @@
  * every draw is restated here.
  *
  * Rasterisation rules this oracle fixes where Vulkan leaves latitude:
+ *   - the perspective division is a product with the correctly rounded reciprocal of w;
  *   - vertices snap to 1/256 pixel (round-to-nearest-even);
  *   - coverage is exact 64-bit integer edge functions at pixel centres with the
  *     top-left rule;
@@ -160,14 +161,17 @@ typedef struct {
 
 static snap_vert project_vertex(const geo_ctx* c, const clip_vert* v) {
     snap_vert r;
-    float ndcx = v->x / v->w, ndcy = v->y / v->w;
+    /* the perspective division: one correctly rounded reciprocal of w, then products (GLSL does not fix the
+       rounding of x / w; a division by a shared scalar is lowered this way by shader compilers) */
+    float rw = 1.0f / v->w;
+    float ndcx = v->x * rw, ndcy = v->y * rw;
     float hw = (float)c->W * 0.5f, hh = (float)c->H * 0.5f;
     float xf = hw * ndcx + hw;
     float yf = -hh * ndcy + hh; /* viewport {y = H, height = -H} */
     r.X = (int32_t)rintf(xf * 256.0f);
     r.Y = (int32_t)rintf(yf * 256.0f);
-    r.z = v->z / v->w;
-    r.inv_w = 1.0f / v->w;
+    r.z = v->z * rw;
+    r.inv_w = rw;
     memcpy(r.uv, v->uv, sizeof(r.uv));
     return r;
 }
@@ -393,8 +397,9 @@ static void draw_meshlet(geo_ctx* c, uint32_t draw_id, uint32_t meshlet_index, u
         v4 clip = m4_mul_v4(u->view_proj, m4_mul_v4(model, p));
         cv[i].x = clip.x; cv[i].y = clip.y; cv[i].z = clip.z; cv[i].w = clip.w;
         memcpy(cv[i].uv, vtx->uv, sizeof(float) * 4);
-        scx[i] = (clip.x / clip.w * 0.5f + 0.5f) * u->screen_width;
-        scy[i] = (clip.y / clip.w * 0.5f + 0.5f) * u->screen_height;
+        float rw = 1.0f / clip.w; /* shader.mesh.glsl:87-88: clip.xy / clip.w, as a product with the reciprocal */
+        scx[i] = (clip.x * rw * 0.5f + 0.5f) * u->screen_width;
+        scy[i] = (clip.y * rw * 0.5f + 0.5f) * u->screen_height;
     }
     for (uint32_t t = 0; t < m->triangle_count; ++t) {
         uint32_t ia = s->meshlet_triangles[m->triangle_offset + t * 3 + 0];

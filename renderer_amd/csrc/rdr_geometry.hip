@@ -384,8 +384,11 @@ struct SnapVert {
     float u0, v0, u1, v1;
 };
 
-RDR_DEV void project_xy(float cx, float cy, float cw, float half_w, float half_h, int32_t& X, int32_t& Y) {
-    const float ndcx = cx / cw, ndcy = cy / cw;
+// rw = 1 / clip.w, correctly rounded: the perspective division of a vertex is one reciprocal and products (GLSL leaves
+// the rounding of x / w to the implementation, and shader compilers lower a division by a shared scalar this way); every
+// quotient by w of the geometry stage (NDC position, depth, the mesh shader's screen position) uses the same rw.
+RDR_DEV void project_xy(float cx, float cy, float rw, float half_w, float half_h, int32_t& X, int32_t& Y) {
+    const float ndcx = cx * rw, ndcy = cy * rw;
     const float xf = half_w * ndcx + half_w;
     const float yf = -half_h * ndcy + half_h; // viewport {y = H, height = -H}
     X = (int32_t)rintf(xf * 256.0f);
@@ -442,7 +445,13 @@ RDR_DEV void emit_fragment(const FrameView& fv, int px, int py, float z, uint32_
     // The result is not used: the atomic is issued and forgotten, so a lane that produces
     // several fragments never waits for a round trip to the L2 (a pre-test load would cost
     // one per fragment).
+#if defined(RDR_EXP_ATOMICS) && RDR_EXP_ATOMICS == 1 // timing experiment: no atomic at all (wrong image)
+    if (key == 1ull) *p = key;
+#elif defined(RDR_EXP_ATOMICS) && RDR_EXP_ATOMICS == 2 // timing experiment: the atomic performed in the XCD's own L2 (wrong image)
+    __hip_atomic_fetch_min(p, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
     __hip_atomic_fetch_min(p, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 
 // (float)v for an edge-function value, correctly rounded like the plain conversion: below 2^53
@@ -688,18 +697,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : (
             const vec4 world = mul_m4(model, mk4(sv.pos_x[vi], sv.pos_y[vi], sv.pos_z[vi], 1.0f));
             const vec4 clip = mul_m4(u.view_proj, world);
             lds.cx[lane] = clip.x; lds.cy[lane] = clip.y; lds.cz[lane] = clip.z; lds.cw[lane] = clip.w;
-            lds.z[lane] = clip.z / clip.w;
-            lds.sx[lane] = (clip.x / clip.w * 0.5f + 0.5f) * u.screen_width;
-            lds.sy[lane] = (clip.y / clip.w * 0.5f + 0.5f) * u.screen_height;
+            const float rw = 1.0f / clip.w;
+            lds.z[lane] = clip.z * rw;
+            lds.sx[lane] = (clip.x * rw * 0.5f + 0.5f) * u.screen_width;
+            lds.sy[lane] = (clip.y * rw * 0.5f + 0.5f) * u.screen_height;
             const bool nc = vert_needs_clip(clip.x, clip.y, clip.z, clip.w);
             int32_t X = 0, Y = 0;
-            if (!nc) project_xy(clip.x, clip.y, clip.w, half_w, half_h, X, Y);
+            if (!nc) project_xy(clip.x, clip.y, rw, half_w, half_h, X, Y);
             lds.X[lane] = X; lds.Y[lane] = Y;
             lds.clip[lane] = nc ? 1u : 0u;
             if constexpr (MASK) {
                 if (at.has_tex) { // perspective-correct uv for the alpha test
                     const float4 uv = sv.uv_sets[vi];
-                    mlds.inv_w[lane] = 1.0f / clip.w;
+                    mlds.inv_w[lane] = rw;
                     mlds.u[lane] = at.uv_set ? uv.z : uv.x;
                     mlds.v[lane] = at.uv_set ? uv.w : uv.y;
                 }
@@ -1079,9 +1089,10 @@ RDR_DEV ClipVert clip_lerp(const ClipVert& in, const ClipVert& out, float din, f
 
 RDR_DEV SnapVert snap_clip_vert(const ClipVert& v, float half_w, float half_h) {
     SnapVert s;
-    project_xy(v.x, v.y, v.w, half_w, half_h, s.X, s.Y);
-    s.z = v.z / v.w;
-    s.inv_w = 1.0f / v.w;
+    const float rw = 1.0f / v.w;
+    project_xy(v.x, v.y, rw, half_w, half_h, s.X, s.Y);
+    s.z = v.z * rw;
+    s.inv_w = rw;
     s.u0 = v.uv[0]; s.v0 = v.uv[1]; s.u1 = v.uv[2]; s.v1 = v.uv[3];
     return s;
 }

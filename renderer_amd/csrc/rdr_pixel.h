@@ -11,11 +11,11 @@ struct BaryDeriv {
     vec3 lambda, ddx, ddy;
 };
 
-// Correctly rounded a / b.  The library is built with exact division throughout, and this is then a plain
-// division; a build with the approximate fp32 division (RDR_FAST_DIVISION, a tuning experiment) still has to
-// divide exactly here: the barycentrics of a triangle many screens large cancel catastrophically and turn a
-// last-bit difference in 1 / w into a few per cent of colour.  The sequence is the hardware's own IEEE one
-// (scale, reciprocal, two Newton steps, residual, fix-up).
+// Correctly rounded a / b, whatever the translation unit is built with.  The shadow pass is built with exact
+// division throughout, and this is then a plain division; the shading pass is built with the approximate fp32
+// division (RDR_FAST_DIVISION) and still has to divide exactly here: the barycentrics of a triangle many screens
+// large cancel catastrophically and turn a last-bit difference in 1 / w into a few per cent of colour.  The
+// sequence is the hardware's own IEEE one (scale, reciprocal, two Newton steps, residual, fix-up).
 #ifdef RDR_FAST_DIVISION
 RDR_DEV float div_exact(float a, float b) {
     bool scaled_d, scaled_n;

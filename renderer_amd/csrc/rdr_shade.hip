@@ -6,10 +6,9 @@
 // assets/shaders/fullscreen_triangle.vert.glsl:7-9 (pixel -> uv), and the sRGB
 // encode an *_SRGB swapchain image performs (lava/src/swapchain.rs:100-115).
 //
-// Built like the rest of the library with correctly rounded division and square root and
-// without contraction: the hardware's fast forms (a few ulp) are amplified by some terms
-// (1 / (4 ndl ndv) at grazing angles, the LOD's log2 near a mip boundary) into 3-5 / 255 on
-// rare pixels, against 0.009 ms saved on the headline frame.
+// Built with the hardware's fast division and square root (the image is held to 2/255, not to bit equality); the
+// divisions of the analytic barycentrics alone stay correctly rounded (div_exact in rdr_pixel.h): a triangle many
+// screens large cancels catastrophically there and turns a last-bit difference into per cents of colour.
 #include "rdr_pixel.h"
 
 namespace {

@@ -167,13 +167,28 @@ RDR_DEV Ray object_ray(const GpuInstance& inst, vec3 o, vec3 d, float tmax) {
     return r;
 }
 
+// Squared distance between a ball's centre and the line o + t d, with a bound on what rounding can have moved it:
+// `oc` = o - centre, `b` = oc . d, `inv_a` = 1 / (d . d).  The textbook discriminant b^2 - a (|oc|^2 - r^2) is a
+// difference of two terms of the size of a |oc|^2 that leaves a r^2: with the origin D = hundreds of radii away
+// (a low sun: the ray parameter goes up to 1000) its rounding error, a few 2^-24 a D^2, is larger than the slack the
+// radii carry.  Here the component of oc across the ray is formed first, l = oc - (b / a) d, and the discriminant
+// is a (r^2 - |l|^2): l's components are wrong by a few 2^-24 |oc|, |l|^2 by 2 |l| times that.
+RDR_DEV float line_distance2(vec3 oc, vec3 d, float b, float inv_a, float cc, float& err) {
+    const float s = b * inv_a;
+    const vec3 l = mk3(oc.x - s * d.x, oc.y - s * d.y, oc.z - s * d.z);
+    const float ll = dot3(l, l);
+    err = 3.814697265625e-6f * sqrtf(cc * ll) + 1.4551915228366852e-11f * cc; // 2^-18 |oc| |l| + 2^-36 |oc|^2
+    return ll;
+}
+
 // What an instance's two balls (GpuInstance::outer_radius) say about a ray in its object space (o, d):
 //   kBallBlocked  the ray is inside the inner ball somewhere beyond tmin and leaves the outer one before tmax: it is
 //                 blocked, no walk needed;
 //   kBallMissed   the ray does not come within the outer ball between tmin and tmax: the instance cannot block it;
 //   kBallWalk     walk the instance, and nothing beyond t_hi (where the ray leaves the outer ball) can be hit.
-// The radii carry their own slack (0.003 % inside, 0.01 % outside) and the parameters another 1 %, far more than
-// rounding moves anything here.
+// The radii carry their own slack (0.003 % inside, 0.01 % outside), the distance between line and centre carries the
+// bound of line_distance2 (a verdict needs the distance to be on its side of the radius by more than that bound;
+// otherwise the instance is walked), and the parameters another 1 %.
 enum BallVerdict { kBallWalk, kBallBlocked, kBallMissed };
 RDR_DEV BallVerdict ball_verdict(float4 ball, float outer_radius, vec3 o, vec3 d, float tmin, float tmax, float& t_hi) {
     t_hi = tmax;
@@ -181,15 +196,19 @@ RDR_DEV BallVerdict ball_verdict(float4 ball, float outer_radius, vec3 o, vec3 d
     const vec3 oc = mk3(o.x - ball.x, o.y - ball.y, o.z - ball.z);
     const float a = dot3(d, d), b = dot3(oc, d), cc = dot3(oc, oc);
     if (!(a > 0.0f)) return kBallWalk;
-    const float disc_out = b * b - a * (cc - outer_radius * outer_radius);
-    if (disc_out < 0.0f) return kBallMissed;
-    const float root_out = sqrtf(disc_out);
-    const float t_leave_out = (root_out - b) / a, t_enter_out = (-root_out - b) / a;
+    const float inv_a = 1.0f / a;
+    float err;
+    const float ll = line_distance2(oc, d, b, inv_a, cc, err);
+    const float r2_out = outer_radius * outer_radius;
+    if (ll - err > r2_out) return kBallMissed;
+    // where the line crosses the outer ball, widened by the bound (so that [t_enter, t_leave] can only grow)
+    const float root_out = sqrtf(a * fmaxf((r2_out + err) - ll, 0.0f));
+    const float t_leave_out = (root_out - b) * inv_a, t_enter_out = (-root_out - b) * inv_a;
     if (t_leave_out * 1.01f + 1e-30f < tmin || t_enter_out * 0.99f - 1e-30f > tmax) return kBallMissed;
     if (t_leave_out >= 0.0f) t_hi = fminf(tmax, t_leave_out * 1.01f + 1e-30f);
-    const float disc_in = b * b - a * (cc - ball.w * ball.w);
-    if (ball.w > 0.0f && disc_in > 0.0f) {
-        const float t_leave_in = (sqrtf(disc_in) - b) / a;
+    const float r2_in = ball.w * ball.w;
+    if (ball.w > 0.0f && ll + err < r2_in) {
+        const float t_leave_in = (sqrtf(a * ((r2_in - err) - ll)) - b) * inv_a; // the inner ball shrunk by the bound
         if (t_leave_in > tmin * 1.01f && t_leave_out < tmax * 0.99f) return kBallBlocked;
     }
     return kBallWalk;
@@ -299,8 +318,12 @@ RDR_DEV bool shadow_any_hit(const SceneView& sv, uint32_t own_instance, bool ski
                     const float4 wb = sv.world_ball[instance];
                     if (wb.w > 0.0f) {
                         const vec3 oc = mk3(o.x - wb.x, o.y - wb.y, o.z - wb.z);
-                        const float a = dot3(d, d), b = dot3(oc, d), cc = dot3(oc, oc) - wb.w * wb.w;
-                        reach = !(b * b - a * cc < 0.0f) && !(b > 0.0f && cc > 0.0f);
+                        const float a = dot3(d, d), b = dot3(oc, d), cc = dot3(oc, oc), r2 = wb.w * wb.w;
+                        float err;
+                        const float ll = line_distance2(oc, d, b, 1.0f / a, cc, err);
+                        // passed by (the line stays outside the ball by more than rounding can account for), or behind
+                        // the origin (moving away from a ball the origin is outside of)
+                        reach = !(ll - err > r2) && !(b > 0.0f && cc > r2 * 1.0001f);
                     }
                 }
                 if (reach) {

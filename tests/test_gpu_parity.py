@@ -288,6 +288,59 @@ def test_sun_candidates_under_sheared_instances(oracle, monkeypatch):
     plain.close()
 
 
+def _cube_mesh():
+    """A closed unit cube (half-extent 1) as six outward-facing quads in one mesh."""
+    faces = [[(1, -1, -1), (1, 1, -1), (1, 1, 1), (1, -1, 1)], [(-1, -1, 1), (-1, 1, 1), (-1, 1, -1), (-1, -1, -1)],
+             [(-1, 1, -1), (-1, 1, 1), (1, 1, 1), (1, 1, -1)], [(-1, -1, 1), (-1, -1, -1), (1, -1, -1), (1, -1, 1)],
+             [(-1, -1, 1), (1, -1, 1), (1, 1, 1), (-1, 1, 1)], [(1, -1, -1), (-1, -1, -1), (-1, 1, -1), (1, 1, -1)]]
+    vs, idx = [], []
+    for f in faces:
+        v, i = synth.quad_mesh(f)
+        n = np.cross(np.subtract(f[1], f[0]), np.subtract(f[3], f[0]))
+        assert np.dot(n, np.mean(f, axis=0)) > 0  # outward
+        idx.append(i + 4 * len(vs))
+        vs.append(v)
+    return np.concatenate(vs), np.concatenate(idx).astype(np.uint32)
+
+
+@pytest.mark.parametrize("elevation", [1 / 150.0, 1 / 400.0])
+def test_far_shadows_of_small_closed_meshes(oracle, elevation):
+    """A low sun: the shadows of a small sphere and a small cube (closed convex meshes, scaled instances) fall on the
+    ground hundreds of radii away, so the shadow rays meet the instances' ball tests with the origin very far from a
+    small ball, where a discriminant of the form b^2 - a c cancels to nothing.  The checker traces every ray through
+    every triangle; a ray wrongly judged to miss (or to be swallowed by) a ball would be a lit (or dark) pixel on the
+    shadow's edge, 65 % of its brightness."""
+    from renderer_amd.scene import Scene
+    sc = Scene()
+    sc.env = synth.default_env()
+    m_ground = sc.add_material(base_color_factor=(0.9, 0.9, 0.9, 1.0), metallic_roughness_normal_occlusion=(0.0, 1.0, 1, 1))
+    gv, gi = synth.grid_mesh([(-520.0, 0.0, -6.0), (-520.0, 0.0, 6.0), (20.0, 0.0, 6.0), (20.0, 0.0, -6.0)], 64, 4)
+    sc.add_draw(sc.append_mesh(gv, [gi]), mat4_trs(), m_ground)
+    v, lods, _ = synth.icosphere(3, lods=1)
+    ball = sc.append_mesh(v, [lods[0]])
+    cv, ci = _cube_mesh()
+    cube = sc.append_mesh(cv, [ci])
+    q = synth._shoemake(0.3, 0.7, 0.2)
+    sc.add_draw(ball, mat4_trs((0.0, 1.0, -1.5), q, (0.25, 0.25, 0.25)), m_ground)
+    sc.add_draw(cube, mat4_trs((2.0, 1.2, 1.5), q, (0.3, 0.3, 0.3)), m_ground)
+    # the sun just above the horizon in +x: an object at height y shades the ground y / elevation further along -x
+    sun = (1.0, elevation, 0.0)
+    reach = 1.0 / elevation
+    for back in (0.85, 1.15):  # two places along the shadows (they span 0.75 .. 1.25 and more of `reach`)
+        sc.camera = Camera((-reach * back, 5.0, 0.0), (0.05, 1.0, 0.02))  # looks straight down (along -direction)
+        o, ovis, g = both(oracle, sc, 480, 270, cull_enabled=False)
+        g.render(sc.camera, sun)
+        o.render_visbuffer(sc.camera, sun)
+        ref = o.shade()
+        img = g.read_color()
+        # the frame must hold both lit and shadowed ground, or the test tests nothing
+        lum = ref[..., :3].astype(int).sum(axis=2)
+        assert (lum < 0.75 * lum.max()).sum() > 200 and (lum > 0.9 * lum.max()).sum() > 200  # (0.35 linear is 0.63 after the sRGB curve)
+        err = np.abs(img.astype(np.int32) - ref.astype(np.int32))
+        assert err.max() <= 2, f"elevation {elevation}, at {back}: {int((err.max(axis=2) > 2).sum())} pixels differ by up to {err.max()} / 255"
+        g.close()
+
+
 def test_known_answer_triangle():
     W = H = 64
     sc = fb_triangle_scene([[(8, 8, 5.0), (8, 40, 5.0), (40, 8, 5.0)]], W, H)
