@@ -150,6 +150,7 @@ struct rdr_renderer {
     uint32_t seen_status[2] = {0, 0};
     uint32_t debug_deferred_capacity = 0xFFFFFFFFu; // test hook: smaller deferred list
     rdr_composite_state* composite = nullptr; // peer-to-peer sort-last exchange, created on first use
+    uint32_t tile_path_rare_mode = 1; // RDR_TILE_PATH_RARE: 0 = always the three tile-path launches, 1 = the one-launch form after a frame without such work, 2 = always the one-launch form (tests)
     uint32_t shadow_defer = 1; // measurement hook RDR_SHADOW_DEFER=0: own-instance walks stay inside k_shadow
     uint32_t convex_skip = 1; // measurement hook RDR_CONVEX_SKIP=0: trace every shadow ray through its own instance; bit 1: inner-ball shortcut
 };
@@ -485,10 +486,17 @@ FrameView make_frame_view(rdr_renderer* r) {
     g.slot_draw = 0;
     g.slot_cull = g.slot_draw + g.draw_blocks;
     g.slot_raster = g.slot_cull + g.cull_blocks * kCullSlots;
+    // the one-launch tile path: a fraction of what fits the device (its barriers need the whole grid resident, also
+    // beside another renderer's), a multiple of the queue segments; on when the last finished frame had no such work
+    g.rare_blocks = r->tile_path_rare_mode ? (std::min(128u, r->resident.tile_path_rare) / 32u) * 32u : 0u;
+    {
+        const uint32_t hint = r->status_host ? r->status_host[2] : 0u;
+        g.tile_path_rare = r->tile_path_rare_mode == 2u ? 1u : ((hint != 0u && (hint & 0xFFu) == 0u) ? 1u : 0u);
+    }
     g.slot_mid = g.slot_raster + (g.raster_blocks + g.raster_mask_blocks) * kRasterSlots;
-    g.slot_frag = g.slot_mid + g.mid_blocks;
+    g.slot_frag = g.slot_mid + std::max(g.mid_blocks, g.rare_blocks);
     g.slot_deferred = g.slot_frag + g.frag_blocks;
-    g.slot_shade = g.slot_deferred + g.deferred_blocks;
+    g.slot_shade = g.slot_deferred + std::max(g.deferred_blocks, g.rare_blocks);
     g.slot_total = g.slot_shade;
     return fv;
 }
@@ -498,8 +506,11 @@ int fetch_counters(rdr_renderer* r, FrameCounters* out) {
     RDR_HIP(hipMemcpy(out, r->counters.ptr + (r->frame_seq & 1u), sizeof(FrameCounters), hipMemcpyDeviceToHost));
     r->seen_status[0] = r->status_host[0]; // this call reports the frame itself
     r->seen_status[1] = r->status_host[1];
-    RDR_CHECK(out->deferred_overflow == 0 && out->setup_overflow == 0 && out->bin_overflow == 0 && out->mid_overflow == 0 && out->frag_overflow == 0,
+    RDR_CHECK(out->deferred_overflow == 0 && out->setup_overflow == 0 && out->bin_overflow == 0 && out->mid_overflow == 0 && out->frag_overflow == 0 &&
+                  (out->sticky_flags & (RDR_FRAME_DEFERRED_OVERFLOW | RDR_FRAME_SETUP_OVERFLOW | RDR_FRAME_BIN_OVERFLOW | RDR_FRAME_MID_OVERFLOW | RDR_FRAME_FRAG_OVERFLOW)) == 0,
               "frame: a tile-path list (deferred triangles, setup records or bins) overflowed; triangles were dropped");
+    RDR_CHECK(out->rare_timeout == 0, "frame: the one-launch tile path gave up waiting for its own workgroups (the device was kept full by other streams); triangles were dropped");
+    RDR_CHECK((out->sticky_flags & RDR_FRAME_LIST_OVERFLOW) == 0, "frame: a work list overflowed");
     RDR_CHECK(out->deep_overflow == 0, "frame: a shadow ray's traversal stack overflowed; its pixel may be lit wrongly");
     RDR_CHECK(out->cmd_count <= r->commands.count && (uint64_t)out->vis_count + out->vis_mask_count <= r->visible.count,
               "frame: a work list overflowed");
@@ -610,6 +621,7 @@ int rdr_create(const rdr_config* cfg, uint32_t width, uint32_t height, const int
         r->status_dev = static_cast<uint32_t*>(dev);
     }
     if (const char* e = std::getenv("RDR_TILE_FLAGS")) r->force_tile_flags = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RDR_TILE_PATH_RARE")) r->tile_path_rare_mode = (uint32_t)std::min(2, std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("RDR_CONVEX_SKIP")) r->convex_skip = std::atoi(e) != 0 ? 1u : 0u;
     if (const char* e = std::getenv("RDR_SUN_CANDIDATES")) r->sun_candidates = std::atoi(e) != 0 ? 1u : 0u; // measurement hook
     if (const char* e = std::getenv("RDR_SHADOW_DEFER")) r->shadow_defer = std::atoi(e) != 0 ? 1u : 0u; // measurement hook
@@ -993,7 +1005,11 @@ int rdr_frame_status(rdr_renderer* r, uint32_t* flags) {
     RDR_HIP(hipStreamSynchronize(r->stream));
     r->seen_status[0] = r->status_host[0];
     r->seen_status[1] = r->status_host[1];
-    *flags = (r->seen_status[0] | r->seen_status[1]) & 0x7Fu;
+    // each word carries the frame it describes: the shading half's only counts if it ran for the last frame
+    const uint32_t seq = r->frame_seq & 0xFFFFFFu;
+    *flags = 0;
+    if ((r->seen_status[0] >> 8) == seq) *flags |= r->seen_status[0] & 0x7Fu;
+    if ((r->seen_status[1] >> 8) == seq) *flags |= r->seen_status[1] & 0x7Fu;
     if (rdr_composite_timed_out(r->composite)) *flags |= RDR_FRAME_PEER_TIMEOUT;
     return 0;
 }
@@ -1059,9 +1075,9 @@ int rdr_get_stats(rdr_renderer* r, rdr_stats* out) {
             st.triangles_tested += p[0]; st.triangles_rasterised += p[1]; st.triangles_big += p[2];
             st.fragments += p[3]; st.vertices_transformed += p[4];
         }
-        for (uint32_t b = 0; b < g.mid_blocks; ++b) st.fragments += slots[g.slot_mid + b];
+        for (uint32_t b = g.slot_mid; b < g.slot_frag; ++b) st.fragments += slots[b];
         for (uint32_t b = 0; b < g.frag_blocks; ++b) st.fragments += slots[g.slot_frag + b];
-        for (uint32_t b = 0; b < g.deferred_blocks; ++b) st.fragments += slots[g.slot_deferred + b];
+        for (uint32_t b = g.slot_deferred; b < g.slot_shade; ++b) st.fragments += slots[b];
         if (r->shaded) st.pixels_covered = fc.pixel_count;
         st.bin_entries = fc.bin_total;
         std::vector<uint32_t> bins((size_t)fv.tiles_x * fv.tiles_y);

@@ -948,7 +948,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : (
 // Mid-sized triangles queued by k_raster: one wave per record, every lane one pixel of each
 // 8x8 stamp, fragments merged with the same atomic as the per-lane scan.  Spreads the pixel
 // work of a meshlet that covers a lot of screen over many waves.
-RDR_DEV void mid_raster_role(const SceneView& sv, const FrameView& fv, uint32_t block, uint32_t n_blocks) {
+RDR_DEV void mid_raster_role(const SceneView& sv, const FrameView& fv, uint32_t block, uint32_t n_blocks, uint32_t stat_slot) {
     __shared__ uint32_t wg_frags[4];
     const uint32_t lane = lane_id();
     // the queue is segmented (FrameCounters::mid_seg): lane s holds the running total up to segment s
@@ -997,7 +997,7 @@ RDR_DEV void mid_raster_role(const SceneView& sv, const FrameView& fv, uint32_t 
         const uint32_t f = wave_sum(frags);
         if (lane == 0) wg_frags[threadIdx.x >> 6] = f;
         __syncthreads();
-        if (threadIdx.x == 0) stat_store(fv, fv.grid.slot_mid + block, wg_frags[0] + wg_frags[1] + wg_frags[2] + wg_frags[3]);
+        if (threadIdx.x == 0) stat_store(fv, stat_slot + block, wg_frags[0] + wg_frags[1] + wg_frags[2] + wg_frags[3]);
     }
 }
 
@@ -1202,14 +1202,14 @@ RDR_DEV void clip_store(ClipLds& l, uint32_t lane, int buf, int i, const ClipVer
     for (int k = 0; k < 4; ++k) l.v[buf][i][4 + k][lane] = c.uv[k];
 }
 
-__global__ __launch_bounds__(64) void k_tile_setup(SceneView sv, FrameView fv) {
-    __shared__ ClipLds clip;
+// One wave's share of the set-up: wave `wave_index` of `n_waves`, with an LDS polygon buffer of its own.
+RDR_DEV void tile_setup_role(const SceneView& sv, const FrameView& fv, ClipLds& clip, uint32_t wave_index, uint32_t n_waves) {
     const uint32_t lane = lane_id();
     const uint32_t count = min(fv.counters->deferred_count, fv.deferred_capacity);
     const float half_w = (float)fv.width * 0.5f, half_h = (float)fv.height * 0.5f;
-    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t stride = n_waves * 64u;
     // whole waves iterate together so that slots can be reserved with one atomic per wave
-    for (uint32_t base_i = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base_i < count; base_i += stride) {
+    for (uint32_t base_i = wave_index * 64u; base_i < count; base_i += stride) {
         const uint32_t di = base_i + lane;
         int n = 0, cur = 0; // vertex count and the buffer that holds the polygon
         bool cull_front = true, masked = false, alpha_draw = false, unclipped = false;
@@ -1283,7 +1283,7 @@ __global__ __launch_bounds__(64) void k_tile_setup(SceneView sv, FrameView fv) {
             const unsigned long long mm = __ballot(to_mid);
             if (mm) {
                 const int mid_leader = __ffsll((long long)mm) - 1;
-                const uint32_t seg = blockIdx.x % kMidSegments, seg_capacity = fv.mid_capacity / kMidSegments;
+                const uint32_t seg = wave_index % kMidSegments, seg_capacity = fv.mid_capacity / kMidSegments;
                 uint32_t base = 0;
                 if ((int)lane == mid_leader) base = atomicAdd(&fv.counters->mid_seg[seg * 32u], (uint32_t)__popcll(mm));
                 base = __shfl(base, mid_leader, 64);
@@ -1314,6 +1314,11 @@ __global__ __launch_bounds__(64) void k_tile_setup(SceneView sv, FrameView fv) {
             count_tiles(fv, t, stored, lane); // the whole wave: wide records are walked by all lanes
         }
     }
+}
+
+__global__ __launch_bounds__(64) void k_tile_setup(SceneView sv, FrameView fv) {
+    __shared__ ClipLds clip;
+    tile_setup_role(sv, fv, clip, blockIdx.x, gridDim.x);
 }
 
 // Bin offsets and the bins.  Every workgroup first repeats the prefix sum over the per-tile counts for itself
@@ -1436,7 +1441,7 @@ RDR_DEV void tile_fill_role(const FrameView& fv, uint32_t block, uint32_t n_bloc
 constexpr uint32_t kFillBlocks = 512;
 __global__ __launch_bounds__(256) void k_mid_fill(SceneView sv, FrameView fv) {
     if (blockIdx.x < kFillBlocks) tile_fill_role(fv, blockIdx.x, kFillBlocks);
-    else mid_raster_role(sv, fv, blockIdx.x - kFillBlocks, fv.grid.mid_blocks);
+    else mid_raster_role(sv, fv, blockIdx.x - kFillBlocks, fv.grid.mid_blocks, fv.grid.slot_mid);
 }
 
 // A workgroup takes jobs: kTileJob records of one tile's bin over one kTilePart x kTilePart piece of the
@@ -1446,8 +1451,41 @@ __global__ __launch_bounds__(256) void k_mid_fill(SceneView sv, FrameView fv) {
 // large alpha-tested triangles would otherwise set the kernel's length alone (interior scene: one
 // 256-thread workgroup per tile with 4 x 4 pixels per thread 0.175 ms for the tile path, this 0.128 ms).
 // A frame with empty bins pays for the resident round only.
+// What the last kernel of a geometry pass owes the frame besides its own work: the sets of list heads and tile
+// counts the next frame will use are zeroed (FrameView::counters_next; spread over the grid), and the pass's status
+// goes where the host sees it without a synchronisation.  Every producer of the lists has finished (earlier
+// kernels), so the overflow counters are final; with two-phase culling a frame has two passes and the flags and the
+// tile-path hint accumulate in the frame's counters, which k_phase_reset leaves alone.
+RDR_DEV void pass_epilogue(const FrameView& fv, uint32_t block, uint32_t n_blocks) {
+    const uint32_t n_words = (uint32_t)(sizeof(FrameCounters) / 4u), n_tiles = fv.tiles_x * fv.tiles_y;
+    for (uint32_t w = block * blockDim.x + threadIdx.x; w < n_words + n_tiles; w += n_blocks * blockDim.x) {
+        if (w < n_words) reinterpret_cast<uint32_t*>(fv.counters_next)[w] = 0u;
+        else {
+            fv.tile_count_next[w - n_words] = 0u;
+            fv.tile_cursor[w - n_words] = 0u; // k_mid_fill is done with it and expects it zero the next time
+        }
+    }
+    if (block == 0 && threadIdx.x == 0) {
+        FrameCounters* c = fv.counters;
+        uint32_t flags = c->sticky_flags;
+        flags |= (c->deferred_overflow || c->rare_timeout) ? RDR_FRAME_DEFERRED_OVERFLOW : 0u;
+        flags |= c->setup_overflow ? RDR_FRAME_SETUP_OVERFLOW : 0u;
+        flags |= c->bin_overflow ? RDR_FRAME_BIN_OVERFLOW : 0u;
+        flags |= c->mid_overflow ? RDR_FRAME_MID_OVERFLOW : 0u;
+        flags |= c->frag_overflow ? RDR_FRAME_FRAG_OVERFLOW : 0u;
+        flags |= (c->cmd_count > fv.command_capacity || (unsigned long long)c->vis_count + c->vis_mask_count > fv.visible_capacity)
+                     ? RDR_FRAME_LIST_OVERFLOW : 0u;
+        c->sticky_flags = flags;
+        uint32_t work = c->tile_work | (c->deferred_count ? 1u : 0u);
+        for (uint32_t sgm = 0; sgm < kMidSegments; ++sgm) work |= c->mid_seg[sgm * 32u] ? 1u : 0u;
+        c->tile_work = work;
+        __hip_atomic_store(&fv.host_status[0], (fv.frame_seq << 8) | flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&fv.host_status[2], (fv.frame_seq << 8) | work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 template <int B>
-__global__ __launch_bounds__((kTilePart / B) * (kTilePart / B)) void k_tile_raster(SceneView sv, FrameView fv) {
+RDR_DEV void tile_raster_role(const SceneView& sv, const FrameView& fv, uint32_t block, uint32_t n_blocks) {
     constexpr int kSide = kTilePart / B, kWaves = kSide * kSide / 64;
     __shared__ SetupTri batch[kTileBatch];
     __shared__ uint32_t batch_index[kTileBatch];
@@ -1455,33 +1493,9 @@ __global__ __launch_bounds__((kTilePart / B) * (kTilePart / B)) void k_tile_rast
     static_assert(kTileJob <= kTileBatch, "a job is staged in one batch");
     uint32_t frags = 0;
     const uint32_t n_listed = min(fv.counters->tile_nonempty, fv.tile_list_capacity);
-    {   // the sets of list heads and tile counts the next frame will use (FrameView::counters_next)
-        const uint32_t n_words = (uint32_t)(sizeof(FrameCounters) / 4u), n_tiles = fv.tiles_x * fv.tiles_y;
-        for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n_words + n_tiles; w += gridDim.x * blockDim.x) {
-            if (w < n_words) reinterpret_cast<uint32_t*>(fv.counters_next)[w] = 0u;
-            else {
-                fv.tile_count_next[w - n_words] = 0u;
-                fv.tile_cursor[w - n_words] = 0u; // k_mid_fill is done with it and expects it zero the next time
-            }
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        // last kernel of the geometry half: every producer of the lists has finished, so the overflow
-        // counters are final; leave the frame's status where the host sees it without a synchronisation
-        const FrameCounters* c = fv.counters;
-        uint32_t flags = 0;
-        flags |= c->deferred_overflow ? RDR_FRAME_DEFERRED_OVERFLOW : 0u;
-        flags |= c->setup_overflow ? RDR_FRAME_SETUP_OVERFLOW : 0u;
-        flags |= c->bin_overflow ? RDR_FRAME_BIN_OVERFLOW : 0u;
-        flags |= c->mid_overflow ? RDR_FRAME_MID_OVERFLOW : 0u;
-        flags |= c->frag_overflow ? RDR_FRAME_FRAG_OVERFLOW : 0u;
-        flags |= (c->cmd_count > fv.command_capacity || (unsigned long long)c->vis_count + c->vis_mask_count > fv.visible_capacity)
-                     ? RDR_FRAME_LIST_OVERFLOW : 0u;
-        __hip_atomic_store(&fv.host_status[0], (fv.frame_seq << 8) | flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
     // Jobs are dealt out by index, a grid's width apart: a shared counter would cost an atomic that returns a
     // value per job, and those serialise on their address (10 000 jobs: 0.1 ms).
-    for (uint32_t this_li = blockIdx.x; this_li < n_listed; this_li += gridDim.x) {
+    for (uint32_t this_li = block; this_li < n_listed; this_li += n_blocks) {
         const uint2 job = fv.tile_list[this_li];
         const uint32_t tile = job.x;
         const uint32_t n_all = fv.tile_count[tile];
@@ -1637,9 +1651,85 @@ __global__ __launch_bounds__((kTilePart / B) * (kTilePart / B)) void k_tile_rast
         if (threadIdx.x == 0) {
             uint32_t total = 0;
             for (int w = 0; w < kWaves; ++w) total += wg_frags[w];
-            stat_store(fv, fv.grid.slot_deferred + blockIdx.x, total);
+            stat_store(fv, fv.grid.slot_deferred + block, total);
         }
     }
+}
+
+template <int B>
+__global__ __launch_bounds__((kTilePart / B) * (kTilePart / B)) void k_tile_raster(SceneView sv, FrameView fv) {
+    pass_epilogue(fv, blockIdx.x, gridDim.x);
+    tile_raster_role<B>(sv, fv, blockIdx.x, gridDim.x);
+}
+
+// The tile path as one launch, for frames that are not expected to need it (the frame before had neither a deferred
+// triangle nor a mid-sized one: the host's hint, FrameCounters::tile_work): every workgroup looks at the frame's own
+// counters and leaves at once when they are empty, which makes the all-small-triangles frame three dependent
+// launches shorter (4-5 us each).  If this frame does have such triangles after all, the same three steps run here
+// behind grid-wide barriers -- slower than the three launches (a small grid, barrier round trips), but correct, and
+// the next frame is launched the usual way.  The grid (FrameView::grid.rare_blocks, a fraction of what fits the
+// device) is resident as a whole, so the barriers cannot wait for a workgroup that has not started, unless other
+// streams keep the device full for as long as kRareWaitTicks: then the pass gives up and the frame is reported
+// as having dropped work (FrameCounters::rare_timeout), never hung.
+constexpr long long kRareWaitTicks = 200000000; // wall_clock64 runs at 100 MHz: 2 s
+RDR_DEV bool rare_grid_barrier(const FrameView& fv, uint32_t n_blocks, uint32_t& round) {
+    __shared__ uint32_t ok;
+    __threadfence(); // this thread's writes, device-wide
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        round += 1u;
+        __hip_atomic_fetch_add(&fv.counters->rare_barrier, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const long long start = wall_clock64();
+        uint32_t good = 1u;
+        while (__hip_atomic_load(&fv.counters->rare_barrier, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < round * n_blocks) {
+            if (__hip_atomic_load(&fv.counters->rare_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - start > kRareWaitTicks) {
+                __hip_atomic_store(&fv.counters->rare_timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                good = 0u;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        ok = good;
+    }
+    __syncthreads();
+    __threadfence(); // the other workgroups' writes, for every thread of this one
+    return ok != 0u;
+}
+
+__global__ __launch_bounds__(256) void k_tile_path_rare(SceneView sv, FrameView fv) {
+    __shared__ ClipLds clip;
+    __shared__ uint32_t any_work;
+    if (threadIdx.x < 64) {
+        const uint32_t lane = threadIdx.x;
+        uint32_t w = lane == 0 ? fv.counters->deferred_count : 0u;
+        if (lane < kMidSegments) w |= fv.counters->mid_seg[lane * 32u];
+        const unsigned long long m = __ballot(w != 0u);
+        if (lane == 0) any_work = m != 0ull ? 1u : 0u;
+    }
+    // the statistics slots of the kernels this launch stands in for: what this pass does not write must read as zero
+    // (workgroup b clears the slots b, b + grid, ... and later writes slot b itself)
+    if (fv.collect_stats && !fv.stat_accumulate && threadIdx.x == 0) {
+        const uint32_t n_mid = fv.grid.slot_frag - fv.grid.slot_mid, n_def = fv.grid.slot_shade - fv.grid.slot_deferred;
+        for (uint32_t i = blockIdx.x; i < n_mid; i += gridDim.x) fv.stat_slots[fv.grid.slot_mid + i] = 0u;
+        for (uint32_t i = blockIdx.x; i < n_def; i += gridDim.x) fv.stat_slots[fv.grid.slot_deferred + i] = 0u;
+    }
+    __syncthreads();
+    if (!any_work) { // the expected case
+        pass_epilogue(fv, blockIdx.x, gridDim.x);
+        return;
+    }
+    uint32_t round = 0;
+    if (threadIdx.x < 64) tile_setup_role(sv, fv, clip, blockIdx.x, gridDim.x);
+    bool ok = rare_grid_barrier(fv, gridDim.x, round);
+    const uint32_t fill_blocks = gridDim.x / 2u;
+    if (ok) {
+        if (blockIdx.x < fill_blocks) tile_fill_role(fv, blockIdx.x, fill_blocks);
+        else mid_raster_role(sv, fv, blockIdx.x - fill_blocks, gridDim.x - fill_blocks, fv.grid.slot_mid + fill_blocks); // slot = this workgroup's index
+    }
+    ok = rare_grid_barrier(fv, gridDim.x, round) && ok;
+    // every producer is done (or the pass has given up, which the epilogue reports): as in k_tile_raster
+    pass_epilogue(fv, blockIdx.x, gridDim.x);
+    if (ok) tile_raster_role<kTileBlock>(sv, fv, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------
@@ -1729,7 +1819,8 @@ __global__ __launch_bounds__(256) void k_phase_reset(FrameView fv) {
     if (gi == 0) {
         FrameCounters* c = fv.counters;
         c->cmd_count = 0; c->vis_count = 0; c->vis_mask_count = 0; c->deferred_count = 0;
-        c->setup_count = 0; c->bin_total = 0;
+        c->setup_count = 0; c->bin_total = 0; c->tile_nonempty = 0;
+        c->rare_barrier = 0; // the late pass's k_tile_path_rare counts its own arrivals
     }
     if (gi < kMidSegments) fv.counters->mid_seg[gi * 32u] = 0u;
     if (gi < kFragSegments) fv.counters->frag_seg[gi * 16u] = 0ull;
@@ -1791,6 +1882,15 @@ int rdr_geometry_residency(GeometryResidency* out, uint32_t fill_lds_bytes) {
     out->alpha_frag = (uint32_t)(n * cus);
     RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tile_raster<kTileBlock>, (kTilePart / kTileBlock) * (kTilePart / kTileBlock), 0));
     out->tile_raster = (uint32_t)(n * cus);
+    {   // the one-launch tile path: static LDS (the clipper's polygon buffer, the rasteriser's batch) + the bin offsets
+        hipFuncAttributes attr;
+        out->tile_path_rare = 0;
+        if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(k_tile_path_rare)) == hipSuccess &&
+            attr.sharedSizeBytes + fill_lds_bytes <= 65536 &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tile_path_rare, 256, fill_lds_bytes) == hipSuccess)
+            out->tile_path_rare = (uint32_t)(n * cus);
+        (void)hipGetLastError();
+    }
     return 0;
 }
 
@@ -1818,6 +1918,11 @@ int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t st
             if (f.touched) hipLaunchKernelGGL((k_raster<true, true>), dim3(f.grid.raster_mask_blocks), dim3(64), 0, stream, sv, f);
             else hipLaunchKernelGGL((k_raster<true, false>), dim3(f.grid.raster_mask_blocks), dim3(64), 0, stream, sv, f);
             hipLaunchKernelGGL(k_alpha_frag, dim3(f.grid.frag_blocks), dim3(256), 0, stream, sv, f);
+        }
+        if (f.grid.tile_path_rare && f.grid.rare_blocks) { // the frame before had nothing for these three: one launch that checks
+            if (mid_event) (void)hipEventRecord(*mid_event, stream);
+            hipLaunchKernelGGL(k_tile_path_rare, dim3(f.grid.rare_blocks), dim3(256), rdr_tile_fill_lds(n_tiles), stream, sv, f);
+            return;
         }
         hipLaunchKernelGGL(k_tile_setup, dim3(1024), dim3(64), 0, stream, sv, f); // also feeds k_mid_raster
         hipLaunchKernelGGL(k_mid_fill, dim3(f.grid.mid_blocks + kFillBlocks), dim3(256), rdr_tile_fill_lds(n_tiles), stream, sv, f);

@@ -117,8 +117,14 @@ struct FrameCounters {
     uint32_t tile_nonempty;   // jobs of the tile rasteriser this pass (length of tile_list)
     uint32_t mid_overflow;
     uint32_t deep_overflow;   // shadow rays whose deep (scratch) stack dropped entries without finding a hit
-    uint32_t _pad0[2];
-    unsigned long long _pad1[16];
+    // Frame-wide (k_phase_reset leaves them alone): the RDR_FRAME_* flags of every geometry pass of the frame so far
+    // (with two-phase culling the early pass's list heads are gone by the time the late pass reports), and whether
+    // any pass had work for the tile path or the mid-sized queue (the host's hint for the next frame's launches).
+    uint32_t sticky_flags;
+    uint32_t tile_work;
+    uint32_t rare_barrier;    // k_tile_path_rare: arrivals at its grid-wide barriers
+    uint32_t rare_timeout;    // k_tile_path_rare: a barrier gave up waiting (reported as RDR_FRAME_DEFERRED_OVERFLOW)
+    unsigned long long _pad1[15];
     // SetupTri records queued for k_mid_raster, per segment of the queue.  Every wave of k_raster
     // reserves its slots with an atomic that returns a value, and same-address atomics serialise
     // (about 10 ns each): the queue is cut into segments with counters 128 bytes apart (word
@@ -328,6 +334,8 @@ struct SceneView {
 // Launch geometry of one frame and where each kernel's workgroups put their statistics.
 struct GridPlan {
     uint32_t draw_blocks, cull_blocks, raster_blocks, raster_mask_blocks, mid_blocks, frag_blocks, deferred_blocks, shade_blocks_x, shade_blocks_y;
+    uint32_t rare_blocks; // grid of k_tile_path_rare (0: never launched), launched instead of the three tile-path kernels when tile_path_rare is set
+    uint32_t tile_path_rare;
     uint32_t slot_draw, slot_cull, slot_raster, slot_mid, slot_frag, slot_deferred, slot_shade, slot_total;
 };
 constexpr uint32_t kCullSlots = 4, kRasterSlots = 8;
@@ -399,7 +407,8 @@ struct FrameView {
     uint32_t lds_stack_limit; // entries of the LDS traversal stack in use (<= 24; lowered only by tests)
     // Frame status in pinned host memory: word 0 is written by the last kernel of the geometry half, word 1 by
     // the last kernel of the shading half, each as frame_seq << 8 | RDR_FRAME_* flags, so that the host learns
-    // of dropped work without synchronising (it looks at the words when the next frame is submitted).
+    // of dropped work without synchronising (it looks at the words when the next frame is submitted).  Word 2:
+    // frame_seq << 8 | 1 when the frame had work for the tile path or the mid-sized queue (FrameCounters::tile_work).
     uint32_t* host_status;
     uint32_t frame_seq;
     uint32_t convex_skip; // 1: shadow rays that leave a closed convex mesh skip that mesh (0 only as a measurement hook)
@@ -456,6 +465,7 @@ void rdr_build_tlas(const rdr_scene_desc& s, const float* transforms, HostBvh& i
 int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t stream, hipEvent_t* ev);
 struct GeometryResidency {
     uint32_t meshlet_cull, raster, raster_mask, mid_raster, alpha_frag, tile_raster; // resident workgroups on the whole device
+    uint32_t tile_path_rare; // k_tile_path_rare (0: does not fit, e.g. its LDS at this frame size)
     uint32_t raster_touch, raster_mask_touch; // k_raster's instantiations that keep the sort-last tile flags
 };
 int rdr_geometry_residency(GeometryResidency* out, uint32_t fill_lds_bytes);
