@@ -150,6 +150,7 @@ struct rdr_renderer {
     uint32_t seen_status[2] = {0, 0};
     uint32_t debug_deferred_capacity = 0xFFFFFFFFu; // test hook: smaller deferred list
     rdr_composite_state* composite = nullptr; // peer-to-peer sort-last exchange, created on first use
+    GridPlan last_grid{}; // launch geometry of the last rdr_render_visbuffer (which form of the tile path ran: the statistics slots follow it)
     uint32_t tile_path_rare_mode = 1; // RDR_TILE_PATH_RARE: 0 = always the three tile-path launches, 1 = the one-launch form after a frame without such work, 2 = always the one-launch form (tests)
     uint32_t shadow_defer = 1; // measurement hook RDR_SHADOW_DEFER=0: own-instance walks stay inside k_shadow
     uint32_t convex_skip = 1; // measurement hook RDR_CONVEX_SKIP=0: trace every shadow ray through its own instance; bit 1: inner-ball shortcut
@@ -926,6 +927,7 @@ int rdr_render_visbuffer(rdr_renderer* r, const float cam_pos[3], const float ca
         ev = r->ring.data() + (size_t)r->cur_slot * rdr_renderer::kEvents;
     }
     if (rdr_launch_geometry(r->sv, fv, r->stream, ev)) return 1;
+    r->last_grid = fv.grid;
     r->frame_rendered = true;
     r->frame_has_tile_flags = fv.touched != nullptr;
     r->shaded = false;
@@ -1062,7 +1064,7 @@ int rdr_get_stats(rdr_renderer* r, rdr_stats* out) {
     if (r->cfg.collect_stats && r->frame_rendered) {
         // sum the per-workgroup slots of the last frame
         const FrameView fv = make_frame_view(r);
-        const GridPlan& g = fv.grid;
+        const GridPlan& g = r->last_grid;
         std::vector<uint32_t> slots(g.slot_total);
         RDR_HIP(hipMemcpy(slots.data(), r->stat_slots.ptr, (size_t)g.slot_total * 4, hipMemcpyDeviceToHost));
         for (uint32_t b = 0; b < g.draw_blocks; ++b) st.draws_visible += slots[g.slot_draw + b];
@@ -1075,9 +1077,12 @@ int rdr_get_stats(rdr_renderer* r, rdr_stats* out) {
             st.triangles_tested += p[0]; st.triangles_rasterised += p[1]; st.triangles_big += p[2];
             st.fragments += p[3]; st.vertices_transformed += p[4];
         }
-        for (uint32_t b = g.slot_mid; b < g.slot_frag; ++b) st.fragments += slots[b];
+        // the tile path's two regions hold the slots of the form that ran: the one-launch form writes (or clears) one per
+        // workgroup of its grid, the three launches one per workgroup of theirs
+        const bool rare = g.tile_path_rare && g.rare_blocks;
+        for (uint32_t b = 0; b < (rare ? g.rare_blocks : g.mid_blocks); ++b) st.fragments += slots[g.slot_mid + b];
         for (uint32_t b = 0; b < g.frag_blocks; ++b) st.fragments += slots[g.slot_frag + b];
-        for (uint32_t b = g.slot_deferred; b < g.slot_shade; ++b) st.fragments += slots[b];
+        for (uint32_t b = 0; b < (rare ? g.rare_blocks : g.deferred_blocks); ++b) st.fragments += slots[g.slot_deferred + b];
         if (r->shaded) st.pixels_covered = fc.pixel_count;
         st.bin_entries = fc.bin_total;
         std::vector<uint32_t> bins((size_t)fv.tiles_x * fv.tiles_y);

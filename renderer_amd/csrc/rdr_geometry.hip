@@ -1706,12 +1706,11 @@ __global__ __launch_bounds__(256) void k_tile_path_rare(SceneView sv, FrameView 
         const unsigned long long m = __ballot(w != 0u);
         if (lane == 0) any_work = m != 0ull ? 1u : 0u;
     }
-    // the statistics slots of the kernels this launch stands in for: what this pass does not write must read as zero
-    // (workgroup b clears the slots b, b + grid, ... and later writes slot b itself)
+    // the statistics slots of the kernels this launch stands in for, one per workgroup of this grid in each of their
+    // regions: what this pass does not write must read as zero (workgroup b clears slot b and later writes it itself)
     if (fv.collect_stats && !fv.stat_accumulate && threadIdx.x == 0) {
-        const uint32_t n_mid = fv.grid.slot_frag - fv.grid.slot_mid, n_def = fv.grid.slot_shade - fv.grid.slot_deferred;
-        for (uint32_t i = blockIdx.x; i < n_mid; i += gridDim.x) fv.stat_slots[fv.grid.slot_mid + i] = 0u;
-        for (uint32_t i = blockIdx.x; i < n_def; i += gridDim.x) fv.stat_slots[fv.grid.slot_deferred + i] = 0u;
+        fv.stat_slots[fv.grid.slot_mid + blockIdx.x] = 0u;
+        fv.stat_slots[fv.grid.slot_deferred + blockIdx.x] = 0u;
     }
     __syncthreads();
     if (!any_work) { // the expected case
