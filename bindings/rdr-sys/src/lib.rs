@@ -108,6 +108,7 @@ extern "C" {
     pub fn rdr_set_shade_rows(r: *mut rdr_renderer, row_lo: u32, row_hi: u32) -> c_int;
     pub fn rdr_set_partition_interleaved(r: *mut rdr_renderer, chunk: u32, rank: u32, world: u32) -> c_int;
     pub fn rdr_set_shade_bands(r: *mut rdr_renderer, band: u32, rank: u32, world: u32) -> c_int;
+    pub fn rdr_set_partition_replication(r: *mut rdr_renderer, min_triangle_pixels: f32) -> c_int;
     pub fn rdr_visbuffer_device_ptr(r: *mut rdr_renderer) -> *mut c_void;
     pub fn rdr_color_device_ptr(r: *mut rdr_renderer) -> *mut c_void;
     pub fn rdr_composite_export(r: *mut rdr_renderer, out: *mut rdr_composite_handle) -> c_int;

@@ -351,6 +351,15 @@ int rdr_set_shade_rows(rdr_renderer* r, uint32_t row_lo, uint32_t row_hi);
  * the row range of rdr_set_shade_rows, and rdr_set_shade_rows replaces it. */
 int rdr_set_partition_interleaved(rdr_renderer* r, uint32_t chunk, uint32_t rank, uint32_t world);
 int rdr_set_shade_bands(rdr_renderer* r, uint32_t band, uint32_t rank, uint32_t world);
+/* A few screen-filling triangles (a floor, a wall) are more pixel work than a rank's whole share, and they sit in
+ * one meshlet.  With a threshold > 0 (and an interleaved share), a draw whose level-0 triangles are estimated to
+ * cover more than `min_triangle_pixels` each on average this frame (object-space mean area x scale^2 x the
+ * projection at the nearest point of its bounding sphere: a function of scene and view, the same on every rank)
+ * is taken by EVERY rank, which rasterises its large triangles only on the rows it shades (rdr_set_shade_bands /
+ * rdr_set_shade_rows).  A rank's buffer is then complete on its own rows, which is all the exchange reads of it,
+ * and the minimum does not care that small triangles of such a draw arrive from several ranks.  0 = off
+ * (default).  Requires the ranks' shade rows to partition the frame. */
+int rdr_set_partition_replication(rdr_renderer* r, float min_triangle_pixels);
 
 /* Device addresses of the W*H uint64 visibility buffer and the W*H*4 RGBA8
  * image, for the collective that composites them (RCCL through the caller). */

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from renderer_amd import Renderer, RendererConfig, synth  # noqa: E402
-from renderer_amd.distributed import DEFAULT_BAND, DEFAULT_CHUNK, instance_range, row_range  # noqa: E402
+from renderer_amd.distributed import DEFAULT_BAND, DEFAULT_CHUNK, DEFAULT_REPLICATE_PIXELS, instance_range, row_range  # noqa: E402
 
 GEOMETRY = ("clear", "draw_cull", "meshlet_cull", "raster", "big_raster")
 SHADING = ("classify", "shadow", "shade")
@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--worlds", default="2,4,8")
     ap.add_argument("--chunk", type=int, default=DEFAULT_CHUNK)
     ap.add_argument("--band", type=int, default=DEFAULT_BAND)
+    ap.add_argument("--replicate", type=float, default=DEFAULT_REPLICATE_PIXELS,
+                    help="interleaved split: draws whose triangles average more pixels than this are drawn by every rank on its own rows (0 = off)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "rank_alone.json"))
     args = ap.parse_args()
     results = []
@@ -77,13 +79,17 @@ def main():
                     if split == "interleaved":
                         r.set_partition(0, n)
                         r.set_partition_interleaved(args.chunk, rank, world)
+                        r.set_shade_bands(args.band, rank, world)  # draws every rank takes are rasterised on the rank's rows
+                        r.set_partition_replication(args.replicate)
                     else:
                         r.set_partition_interleaved(DEFAULT_CHUNK, 0, 1)
+                        r.set_partition_replication(0.0)
                         r.set_partition(*instance_range(n, rank, world))
-                    r.set_shade_rows(0, h)
+                        r.set_shade_rows(0, h)
                     g = timed(r, args.frames, True)
                     # shading of the rank's rows of the complete frame
                     r.set_partition_interleaved(DEFAULT_CHUNK, 0, 1)
+                    r.set_partition_replication(0.0)
                     r.set_partition(0, n)
                     if split == "interleaved":
                         r.set_shade_bands(args.band, rank, world)
@@ -101,7 +107,7 @@ def main():
                     summary[key] = {"max": max(vals), "mean": mean, "max_over_mean": max(vals) / mean if mean else None}
                 frame = [row["geometry_ms"] + row["shading_ms"] for row in rows]
                 summary["frame_ms"] = {"max": max(frame), "mean": sum(frame) / len(frame), "max_over_mean": max(frame) / (sum(frame) / len(frame))}
-                results.append({"scene": name, "world": world, "split": split, "chunk": args.chunk, "band": args.band,
+                results.append({"scene": name, "world": world, "split": split, "chunk": args.chunk, "band": args.band, "replicate_pixels": args.replicate if split == "interleaved" else 0.0,
                                 "one_gpu": whole, "ranks": rows, "summary": summary})
                 print(f"N={world} {split:11s} geometry max/mean {summary['geometry_ms']['max_over_mean']:.3f} (max {summary['geometry_ms']['max']:.3f} ms)  "
                       f"shading max/mean {summary['shading_ms']['max_over_mean']:.3f} (max {summary['shading_ms']['max']:.3f} ms)  "

@@ -136,6 +136,8 @@ struct rdr_renderer {
     uint32_t part_lo = 0, part_hi = 0xFFFFFFFFu;
     uint32_t row_lo = 0, row_hi = 0xFFFFFFFFu;
     uint32_t part_chunk = 64, part_rank = 0, part_world = 1; // rdr_set_partition_interleaved
+    float replicate_pixels = 0.0f;                           // rdr_set_partition_replication
+    DeviceBuffer<float> mesh_tri_area;
     uint32_t band_shift = 5, band_rank = 0, band_world = 1;  // rdr_set_shade_bands
     uint32_t meshlet_visibility_count = 0;
     uint32_t lds_stack_limit = 24;
@@ -409,6 +411,7 @@ FrameView make_frame_view(rdr_renderer* r) {
     fv.width = r->width; fv.height = r->height;
     fv.part_lo = r->part_lo; fv.part_hi = r->part_hi;
     fv.part_chunk = r->part_chunk; fv.part_rank = r->part_rank; fv.part_world = r->part_world;
+    fv.replicate_pixels = r->replicate_pixels;
     fv.row_lo = std::min(r->row_lo, r->height);
     fv.row_hi = std::min(r->row_hi, r->height);
     fv.band_shift = r->band_shift; fv.band_rank = r->band_rank; fv.band_world = r->band_world;
@@ -706,6 +709,26 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
         if (r->materials.upload(mats.data(), mats.size())) return 1;
     }
     if (r->transforms.upload(s.global_transforms, (size_t)s.transform_count * 16)) return 1;
+    {
+        // mean area of a level-0 triangle per mesh, in object space (what rdr_set_partition_replication's estimate starts from)
+        std::vector<float> area(std::max<uint32_t>(s.mesh_count, 1u), 0.0f);
+        for (uint32_t mi = 0; mi < s.mesh_count; ++mi) {
+            const rdr_mesh& m = s.meshes[mi];
+            const uint32_t end = mi + 1 < s.mesh_count ? s.meshes[mi + 1].index_offset : s.index_count;
+            double sum = 0.0;
+            uint32_t n = 0;
+            for (uint32_t i = m.index_offset; i + 2 < end; i += 3, ++n) {
+                const float* a = s.vertices[m.vertex_offset + s.indices[i]].p;
+                const float* b = s.vertices[m.vertex_offset + s.indices[i + 1]].p;
+                const float* c = s.vertices[m.vertex_offset + s.indices[i + 2]].p;
+                const double e1[3] = {(double)b[0] - a[0], (double)b[1] - a[1], (double)b[2] - a[2]}, e2[3] = {(double)c[0] - a[0], (double)c[1] - a[1], (double)c[2] - a[2]};
+                const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+                sum += 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+            }
+            area[mi] = n ? (float)(sum / n) : 0.0f;
+        }
+        if (r->mesh_tri_area.upload(area.data(), area.size())) return 1;
+    }
     if (r->draw_lod.alloc(s.draw_count) || r->draw_frame.alloc(std::max<size_t>(s.draw_count, 1)) || r->draw_visible.alloc(std::max<size_t>(s.draw_count, 1)) ||
         r->meshlet_bits.alloc(((size_t)s.meshlet_visibility_count + 31) / 32 + 1)) return 1;
     // nothing was visible "last frame": the first frame's early phase draws nothing, its late phase everything
@@ -835,6 +858,7 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
     sv.materials = r->materials.ptr;
     sv.transforms = r->transforms.ptr;
     sv.instance_draw = r->instance_draw.ptr;
+    sv.mesh_tri_area = r->mesh_tri_area.ptr;
     sv.draw_lod = r->draw_lod.ptr;
     sv.draw_frame = r->draw_frame.ptr;
     sv.tri_table = r->tri_table.ptr;
@@ -894,6 +918,13 @@ int rdr_set_partition_interleaved(rdr_renderer* r, uint32_t chunk, uint32_t rank
     RDR_CHECK(world >= 1 && rank < world, "rdr_set_partition_interleaved: rank must be below world");
     RDR_CHECK(chunk >= 64 && chunk % 64 == 0 && chunk <= (1u << 20), "rdr_set_partition_interleaved: chunk must be a multiple of 64, at most 2^20");
     r->part_chunk = chunk; r->part_rank = rank; r->part_world = world;
+    return 0;
+}
+
+int rdr_set_partition_replication(rdr_renderer* r, float min_triangle_pixels) {
+    RDR_CHECK(r, "rdr_set_partition_replication: renderer is null");
+    RDR_CHECK(min_triangle_pixels >= 0.0f, "rdr_set_partition_replication: the threshold must not be negative (0 switches it off)");
+    r->replicate_pixels = min_triangle_pixels;
     return 0;
 }
 

@@ -80,10 +80,11 @@ RDR_DEV bool sphere_occluded(const FrameView& fv, vec3 c, float r) {
 }
 
 // The meshlets [k_lo, k_hi) of draw `di` that belong to this renderer's sort-last share, as spans f(lo, hi) of at
-// most one chunk each: everything, or (FrameView::part_world > 1) the chunks j with (j + di) % world == rank.
+// most one chunk each: everything (no interleaving, or a draw every rank draws), or (FrameView::part_world > 1) the
+// chunks j with (j + di) % world == rank.
 template <typename F>
-RDR_DEV void own_spans(const FrameView& fv, uint32_t di, uint32_t k_lo, uint32_t k_hi, F f) {
-    if (fv.part_world <= 1u) {
+RDR_DEV void own_spans(const FrameView& fv, uint32_t di, uint32_t k_lo, uint32_t k_hi, bool everything, F f) {
+    if (fv.part_world <= 1u || everything) {
         if (k_hi > k_lo) f(k_lo, k_hi);
         return;
     }
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void k_draw_cull(SceneView sv, FrameView fv) {
     const uint32_t lane = lane_id();
     const rdr_ubo& u = fv.ubo;
 
-    uint32_t ncmd = 0, k_lo = 0, k_hi = 0, lod_meshlet_offset = 0, vis_off = 0, was_visible = 0;
+    uint32_t ncmd = 0, k_lo = 0, k_hi = 0, lod_meshlet_offset = 0, vis_off = 0, was_visible = 0, replicated = 0;
     float max_scale = 0.0f;
     bool emitted = false;
     if (di < sv.draw_count) {
@@ -142,10 +143,20 @@ __global__ __launch_bounds__(256) void k_draw_cull(SceneView sv, FrameView fv) {
             vis_off = d.meshlet_visibility_offset;
             // this renderer's sort-last share, in meshlet-instance ids
             const uint32_t lo = max(vis_off, fv.part_lo), hi = min(vis_off + L.meshlet_count, fv.part_hi);
+            if (fv.part_world > 1u && fv.replicate_pixels > 0.0f) {
+                // mean projected area of a triangle of the selected level, at the sphere's nearest point: object-space
+                // area x scale^2 x (pixels per unit at that depth)^2; coarser levels have as many times larger triangles
+                // as they have fewer meshlets
+                const float zmin = fmaxf(c.z - radius, u.near_plane);
+                const float ppu = 0.5f * u.screen_height * u.proj[5] / zmin;
+                const float area = sv.mesh_tri_area[d.mesh_index] * (max_scale * max_scale) * (ppu * ppu) *
+                                   ((float)mesh->lods[0].meshlet_count / (float)max(L.meshlet_count, 1u));
+                replicated = area > fv.replicate_pixels ? 1u : 0u; // the same verdict on every rank: it depends on the scene and the view only
+            }
             if (hi > lo) {
                 k_lo = lo - vis_off;
                 k_hi = hi - vis_off;
-                own_spans(fv, di, k_lo, k_hi, [&](uint32_t a, uint32_t b) { ncmd += (b - a + 63u) / 64u; });
+                own_spans(fv, di, k_lo, k_hi, replicated != 0u, [&](uint32_t a, uint32_t b) { ncmd += (b - a + 63u) / 64u; });
             }
             emitted = true;
         }
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(256) void k_draw_cull(SceneView sv, FrameView fv) {
     base = __shfl(base, 0, 64);
     uint32_t slot = base + incl - ncmd;
     if (ncmd)
-        own_spans(fv, di, k_lo, k_hi, [&](uint32_t a, uint32_t b) {
+        own_spans(fv, di, k_lo, k_hi, replicated != 0u, [&](uint32_t a, uint32_t b) {
             for (uint32_t k = a; k < b; k += 64u, ++slot) {
                 if (slot >= fv.command_capacity) return;
                 CullCommand cmd;
@@ -178,7 +189,8 @@ __global__ __launch_bounds__(256) void k_draw_cull(SceneView sv, FrameView fv) {
                 cmd.instance_first = vis_off + k;
                 cmd.max_scale = max_scale;
                 cmd.late_draw_visibility = was_visible;
-                cmd._pad[0] = cmd._pad[1] = 0;
+                cmd.replicated = replicated;
+                cmd._pad = 0;
                 fv.commands[slot] = cmd;
             }
         });
@@ -237,12 +249,13 @@ __global__ __launch_bounds__(1024) void k_meshlet_cull(SceneView sv, FrameView f
         const uint32_t ci = c0 + wave;
         bool accept = false;
         uint32_t draw_id = 0, first = 0, instance_first = 0, tri_count = 0, count = 0, masked = 0;
-        uint32_t model_index = 0, mesh_vertex_offset = 0, m_vertex_offset = 0, m_triangle_offset = 0, m_counts = 0;
+        uint32_t model_index = 0, mesh_vertex_offset = 0, m_vertex_offset = 0, m_triangle_offset = 0, m_counts = 0, replicated = 0;
         bool emit = false;
         if (ci < cmd_count) {
             const CullCommand* cp = &fv.commands[__builtin_amdgcn_readfirstlane(ci)];
             draw_id = cp->draw_id; first = cp->meshlet_first; count = cp->count;
             instance_first = cp->instance_first;
+            replicated = cp->replicated;
             const float max_scale = cp->max_scale;
             const rdr_mesh_draw d = sv.draws[draw_id];
             model_index = d.model_index;
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(1024) void k_meshlet_cull(SceneView sv, FrameView f
                 const rdr_meshlet m = sv.meshlets[first + lane];
                 tri_count = m.triangle_count;
                 m_vertex_offset = m.vertex_offset; m_triangle_offset = m.triangle_offset;
-                m_counts = (uint32_t)m.vertex_count | ((uint32_t)m.triangle_count << 16);
+                m_counts = (uint32_t)m.vertex_count | ((uint32_t)m.triangle_count << 16) | (replicated ? 0x80000000u : 0u);
                 const vec4 cw = mul_m4(model, mk4(m.center[0], m.center[1], m.center[2], 1.0f));
                 const vec4 cv = mul_m4(u.view, cw);
                 const vec3 cc = mk3(cv.x, cv.y, cv.z);
@@ -668,7 +681,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : (
     uint32_t vi_next = 0;
     if (blockIdx.x < vis_count) {
         vm_next = fv.visible[MASK ? fv.visible_capacity - 1u - blockIdx.x : blockIdx.x];
-        if (lane < (vm_next.counts & 0xFFFFu)) vi_next = sv.meshlet_vertices[vm_next.vertex_offset + lane] + vm_next.mesh_vertex_offset;
+        if (lane < (vm_next.counts & 0xFFu)) vi_next = sv.meshlet_vertices[vm_next.vertex_offset + lane] + vm_next.mesh_vertex_offset;
     }
     for (uint32_t mi = blockIdx.x; mi < vis_count; mi += gridDim.x) {
         const VisibleMeshlet vm = vm_next;
@@ -676,7 +689,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : (
         const bool has_next = mi + gridDim.x < vis_count;
         if (has_next) vm_next = fv.visible[MASK ? fv.visible_capacity - 1u - (mi + gridDim.x) : mi + gridDim.x];
         m.vertex_offset = vm.vertex_offset; m.triangle_offset = vm.triangle_offset;
-        m.vertex_count = vm.counts & 0xFFFFu; m.triangle_count = vm.counts >> 16;
+        m.vertex_count = vm.counts & 0xFFu; m.triangle_count = (vm.counts >> 16) & 0xFFu;
         const uint32_t mesh_vertex_offset = vm.mesh_vertex_offset;
         float model[16];
         load_m4(sv.transforms + (size_t)vm.model_index * 16, model);
@@ -717,7 +730,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : (
         }
         __syncthreads();
         if (TOUCH) touch_meshlet(fv, lane < m.vertex_count && lds.clip[lane] == 0u, lds.X, lds.Y, lane);
-        if (has_next && lane < (vm_next.counts & 0xFFFFu)) // in flight during the triangle phase
+        if (has_next && lane < (vm_next.counts & 0xFFu)) // in flight during the triangle phase
             vi_next = sv.meshlet_vertices[vm_next.vertex_offset + lane] + vm_next.mesh_vertex_offset;
 
         // Triangle phase 1: the mesh shader's cull tests, two triangles per lane; the survivors (about
@@ -924,7 +937,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : (
                             }
                             dt->id = (vm.instance << 7) | ti;
                             dt->draw_id = vm.draw_id;
-                            dt->_pad[0] = dt->_pad[1] = 0;
+                            dt->replicated = vm.counts >> 31;
+                            dt->_pad = 0;
                         } else {
                             atomicAdd(&fv.counters->deferred_overflow, 1u);
                         }
@@ -1133,9 +1147,11 @@ RDR_DEV long long edge_max(const EdgeEq& q, int w, int h) {
 // Does the triangle possibly cover a pixel centre of tile (tx, ty)?  Box test plus the
 // three edges evaluated at their most favourable tile corner.  Deterministic: the
 // counting and the filling kernel must agree.
-RDR_DEV bool tile_touched(const SetupTri& t, uint32_t tx, uint32_t ty) {
+RDR_DEV bool tile_touched(const FrameView& fv, const SetupTri& t, uint32_t tx, uint32_t ty) {
     const int x0 = (int)tx * kTile, y0 = (int)ty * kTile;
     if ((int)t.px1 < x0 || (int)t.px0 > x0 + kTile - 1 || (int)t.py1 < y0 || (int)t.py0 > y0 + kTile - 1) return false;
+    // a triangle every sort-last rank draws is rasterised on this rank's rows only
+    if ((t.masked & 4u) && !rdr_rows_owned(fv, (uint32_t)max(y0, (int)t.py0), (uint32_t)min(y0 + kTile - 1, (int)t.py1))) return false;
     const EdgeEq e01 = make_edge(t.X0, t.Y0, t.X1, t.Y1, x0, y0);
     const EdgeEq e12 = make_edge(t.X1, t.Y1, t.X2, t.Y2, x0, y0);
     const EdgeEq e20 = make_edge(t.X2, t.Y2, t.X0, t.Y0, x0, y0);
@@ -1160,7 +1176,7 @@ RDR_DEV void count_tiles(const FrameView& fv, const SetupTri& t, bool valid, uin
     }
     if (n_tiles <= kLaneTiles)
         for (uint32_t q = 0; q < n_tiles; ++q)
-            if (tile_touched(t, tx0 + q % tw, ty0 + q / tw)) atomicAdd(&fv.tile_count[(ty0 + q / tw) * fv.tiles_x + tx0 + q % tw], 1u);
+            if (tile_touched(fv, t, tx0 + q % tw, ty0 + q / tw)) atomicAdd(&fv.tile_count[(ty0 + q / tw) * fv.tiles_x + tx0 + q % tw], 1u);
     unsigned long long wide = __ballot(n_tiles > kLaneTiles);
     while (wide) {
         const int src = __ffsll((long long)wide) - 1;
@@ -1171,11 +1187,12 @@ RDR_DEV void count_tiles(const FrameView& fv, const SetupTri& t, bool valid, uin
         const uint32_t lo = __shfl((uint32_t)t.px0 | ((uint32_t)t.py0 << 16), src, 64);
         const uint32_t hi = __shfl((uint32_t)t.px1 | ((uint32_t)t.py1 << 16), src, 64);
         w.px0 = (uint16_t)lo; w.py0 = (uint16_t)(lo >> 16); w.px1 = (uint16_t)hi; w.py1 = (uint16_t)(hi >> 16);
+        w.masked = __shfl(t.masked, src, 64);
         const uint32_t wx0 = w.px0 / kTile, wy0 = w.py0 / kTile, ww = w.px1 / kTile - wx0 + 1u;
         const uint32_t wn = ww * (w.py1 / kTile - wy0 + 1u);
         for (uint32_t q = lane; q < wn; q += 64u) {
             const uint32_t tx = wx0 + q % ww, ty = wy0 + q / ww;
-            if (tile_touched(w, tx, ty)) atomicAdd(&fv.tile_count[ty * fv.tiles_x + tx], 1u);
+            if (tile_touched(fv, w, tx, ty)) atomicAdd(&fv.tile_count[ty * fv.tiles_x + tx], 1u);
         }
     }
 }
@@ -1213,11 +1230,12 @@ RDR_DEV void tile_setup_role(const SceneView& sv, const FrameView& fv, ClipLds& 
         const uint32_t di = base_i + lane;
         int n = 0, cur = 0; // vertex count and the buffer that holds the polygon
         bool cull_front = true, masked = false, alpha_draw = false, unclipped = false;
-        uint32_t id = 0, draw_id = 0;
+        uint32_t id = 0, draw_id = 0, replicated = 0;
         if (di < count) {
             const DeferredTriangle* dt = &fv.deferred[di];
             draw_id = dt->draw_id;
             id = dt->id;
+            replicated = dt->replicated;
             const rdr_mesh_draw d = sv.draws[draw_id];
             cull_front = d.alpha_mode == 0u;
             alpha_draw = d.alpha_mode == 1u;
@@ -1269,7 +1287,7 @@ RDR_DEV void tile_setup_role(const SceneView& sv, const FrameView& fv, ClipLds& 
                 ok = make_setup(fv, s0, sp, sn, cull_front, t, mk);
                 sp = sn;
             }
-            t.id = id; t.draw_id = draw_id; t.masked = (masked ? 1u : 0u) | (alpha_draw ? 2u : 0u);
+            t.id = id; t.draw_id = draw_id; t.masked = (masked ? 1u : 0u) | (alpha_draw ? 2u : 0u) | (replicated ? 4u : 0u);
             // Alpha-tested triangles that k_raster<true> could not enumerate in a lane but that fit a wave
             // (unclipped, small extent, box within the mid limit) are handed on to k_mid_raster, which runs
             // after this kernel: same record, same queue as the opaque ones k_raster<false> queues itself.
@@ -1396,7 +1414,7 @@ RDR_DEV void tile_fill_role(const FrameView& fv, uint32_t block, uint32_t n_bloc
         if (nt <= kLaneTiles)
             for (uint32_t q = 0; q < nt; ++q) {
                 const uint32_t tx = tx0 + q % tw, ty = ty0 + q / tw;
-                if (!tile_touched(t, tx, ty)) continue;
+                if (!tile_touched(fv, t, tx, ty)) continue;
                 const uint32_t tile = ty * fv.tiles_x + tx;
                 const uint32_t slot = tile_off[tile] + atomicAdd(&fv.tile_cursor[tile], 1u);
                 if (slot < fv.bin_capacity) fv.bin_entries[slot] = i;
@@ -1418,7 +1436,7 @@ RDR_DEV void tile_fill_role(const FrameView& fv, uint32_t block, uint32_t n_bloc
                 for (int k = 0; k < 4; ++k) {
                     const uint32_t q = q0 + 64u * k;
                     const uint32_t tx = wx0 + q % ww, ty = wy0 + q / ww;
-                    touched[k] = q < wn && tile_touched(w, tx, ty);
+                    touched[k] = q < wn && tile_touched(fv, w, tx, ty);
                     tiles[k] = ty * fv.tiles_x + tx;
                 }
 #pragma unroll
@@ -1511,6 +1529,8 @@ RDR_DEV void tile_raster_role(const SceneView& sv, const FrameView& fv, uint32_t
         const int tile_y0 = (int)(tile / fv.tiles_x) * kTile + (int)(part / (kTile / kTilePart)) * kTilePart;
         const int bx0 = tile_x0 + (int)(threadIdx.x % kSide) * B, by0 = tile_y0 + (int)(threadIdx.x / kSide) * B;
         const bool block_on_screen = bx0 < (int)fv.width && by0 < (int)fv.height;
+        // triangles every sort-last rank draws are rasterised on this rank's rows only (a block's rows lie in one band)
+        const bool rows_mine = rdr_rows_owned(fv, (uint32_t)by0, (uint32_t)min(by0 + B - 1, (int)fv.height - 1));
         unsigned long long keys[B * B];
         uint32_t on_screen = 0; // bit j * B + i: pixel (bx0 + i, by0 + j) exists
 #pragma unroll
@@ -1535,6 +1555,7 @@ RDR_DEV void tile_raster_role(const SceneView& sv, const FrameView& fv, uint32_t
             for (uint32_t k = 0; k < nb; ++k) {
                 const SetupTri& t = batch[k];
                 if ((int)t.px1 < bx0 || (int)t.px0 > bx0 + (B - 1) || (int)t.py1 < by0 || (int)t.py0 > by0 + (B - 1)) continue;
+                if ((t.masked & 4u) && !rows_mine) continue;
                 const EdgeEq e01 = make_edge(t.X0, t.Y0, t.X1, t.Y1, bx0, by0); // weight of v2
                 const EdgeEq e12 = make_edge(t.X1, t.Y1, t.X2, t.Y2, bx0, by0); // weight of v0
                 const EdgeEq e20 = make_edge(t.X2, t.Y2, t.X0, t.Y0, bx0, by0); // weight of v1

@@ -39,7 +39,8 @@ struct CullCommand {
     float max_scale;         // largest column length of the draw's model matrix
     uint32_t late_draw_visibility; // occlusion culling, late phase: the draw was visible last frame (so its
                                    // meshlets with their bit set were already drawn by the early phase)
-    uint32_t _pad[2];
+    uint32_t replicated;           // sort-last: every rank draws this draw (FrameView::replicate_pixels)
+    uint32_t _pad;
 };
 static_assert(sizeof(CullCommand) == 32, "CullCommand must be 32 bytes");
 
@@ -53,7 +54,7 @@ struct VisibleMeshlet {
     uint32_t model_index;        // of the draw
     uint32_t vertex_offset;      // of the meshlet, into meshlet_vertices
     uint32_t triangle_offset;    // of the meshlet, into meshlet_triangles
-    uint32_t counts;             // vertex_count | triangle_count << 16
+    uint32_t counts;             // vertex_count | triangle_count << 16 | bit 31: of a draw every sort-last rank draws
     uint32_t mesh_vertex_offset; // of the mesh, added to every meshlet vertex index
 };
 static_assert(sizeof(VisibleMeshlet) == 32, "VisibleMeshlet layout");
@@ -65,7 +66,8 @@ struct DeferredTriangle {
     float uv[3][4];
     uint32_t id;      // (instance << 7) | triangle
     uint32_t draw_id; // for the alpha test
-    uint32_t _pad[2];
+    uint32_t replicated; // of a draw every sort-last rank draws: rasterised on this rank's rows only
+    uint32_t _pad;
 };
 static_assert(sizeof(DeferredTriangle) == 112, "DeferredTriangle layout");
 
@@ -77,7 +79,8 @@ struct SetupTri {
     uint32_t id;
     uint32_t draw_id;
     uint16_t px0, py0, px1, py1; // covered pixel box, clamped to the screen
-    uint32_t masked;             // bit 0: SetupMask holds uv (alpha-tested draw with a texture); bit 1: alpha-tested draw
+    uint32_t masked;             // bit 0: SetupMask holds uv (alpha-tested draw with a texture); bit 1: alpha-tested draw;
+                                 // bit 2: of a draw every sort-last rank draws (only this rank's rows are rasterised)
     uint32_t _pad;
 };
 static_assert(sizeof(SetupTri) == 64, "SetupTri layout");
@@ -303,6 +306,7 @@ struct SceneView {
     const rdr_material* materials;
     const float* transforms;
     const uint32_t* instance_draw; // meshlet instance -> draw id
+    const float* mesh_tri_area;    // per mesh: mean area of a level-0 triangle in object space (FrameView::replicate_pixels)
     const float4* instance_ball;   // per draw: see GpuInstance::outer_radius
     // Sun occluder candidates (k_sun_candidates, for one sun direction and one set of transforms): the instances
     // that could block a sun ray starting anywhere on draw d are tlas_items[sun_cand_base + d * kSunCandidates ..]
@@ -357,6 +361,12 @@ struct FrameView {
     // Interleaved sort-last share on top of the range (part_world > 1): chunk j of draw d (chunks of part_chunk
     // consecutive meshlets of the draw's level of detail) belongs to rank (j + d) % part_world.
     uint32_t part_chunk, part_rank, part_world;
+    // > 0 (and part_world > 1): a draw whose triangles are estimated to cover more than this many pixels each on
+    // average is rasterised by every rank (all its meshlets), and its large triangles (the tile path) only on the rows
+    // the rank shades: what a rank's buffer is read for are its own rows, and the minimum does not care how many ranks
+    // contribute a key.  Deals the pixel work of a few screen-filling triangles out by rows instead of leaving it with
+    // the one rank whose share holds their meshlet.
+    float replicate_pixels;
     // The rows this renderer shades, as `shade_rows` virtual rows: a contiguous range (band_world <= 1: virtual
     // row v is row row_lo + v) or every band_world-th band of (1 << band_shift) rows starting with band band_rank.
     uint32_t row_lo, row_hi;
@@ -431,6 +441,13 @@ __host__ __device__ inline uint32_t rdr_shade_row(const FrameView& fv, uint32_t 
     if (fv.band_world <= 1u) return fv.row_lo + v;
     const uint32_t band = v >> fv.band_shift;
     return (((band * fv.band_world + fv.band_rank) << fv.band_shift) | (v & ((1u << fv.band_shift) - 1u)));
+}
+// Does the renderer shade any of the frame rows y0 .. y1 (inclusive)?
+__host__ __device__ inline bool rdr_rows_owned(const FrameView& fv, uint32_t y0, uint32_t y1) {
+    if (fv.band_world <= 1u) return y1 >= fv.row_lo && y0 < fv.row_hi;
+    const uint32_t b0 = y0 >> fv.band_shift, b1 = y1 >> fv.band_shift;
+    // the first band at or after b0 that belongs to band_rank
+    return (fv.band_rank + fv.band_world - b0 % fv.band_world) % fv.band_world <= b1 - b0;
 }
 // Rows of a frame of `height` rows that belong to rank `rank` of `world` when bands of (1 << shift) rows are dealt round-robin.
 inline uint32_t rdr_band_rows(uint32_t height, uint32_t shift, uint32_t rank, uint32_t world) {

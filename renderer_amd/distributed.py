@@ -15,6 +15,9 @@ Two ways to split the work (``split``):
                  rotated by the draw index, and the frame's rows in bands of ``band`` rows dealt round-robin.
                  Meshlet-instance ids follow the draw order, which for an instanced scene is a spatial order:
                  dealing small pieces out evens both the raster and the shading work between the ranks.
+                 Draws made of a few screen-filling triangles (``replicate_pixels``: mean projected triangle
+                 area) are drawn by every rank, each on the rows it shades: their pixel work cannot be dealt
+                 out by meshlets.
 ``contiguous``   rank k takes the k-th N-th of the meshlet-instance ids and the k-th N-th of the rows
                  (on the bench field at two ranks: 72 % of the fragments on rank 0, 88 % of the covered
                  pixels on rank 1).
@@ -46,6 +49,7 @@ def row_range(height, rank, world):
 
 DEFAULT_CHUNK = 64  # meshlets per dealt chunk: one cull command
 DEFAULT_BAND = 32   # rows per dealt band: one tile row of the peer-to-peer exchange
+DEFAULT_REPLICATE_PIXELS = 2048.0  # draws whose triangles average more pixels than this are drawn by every rank, on its own rows
 
 
 def band_spans(height, band, rank, world):
@@ -191,7 +195,7 @@ class SortLastFrame:
     CPU oracle with host tensors in the tests)."""
 
     def __init__(self, renderer, n_instances, height, rank, world, vis_tensor, color_tensor, composite="auto",
-                 split="interleaved", chunk=DEFAULT_CHUNK, band=DEFAULT_BAND):
+                 split="interleaved", chunk=DEFAULT_CHUNK, band=DEFAULT_BAND, replicate_pixels=DEFAULT_REPLICATE_PIXELS):
         self.r, self.rank, self.world, self.height = renderer, rank, world, height
         self.vis, self.color = vis_tensor, color_tensor
         assert composite in ("auto", "p2p", "reduce_scatter", "all_reduce")
@@ -202,10 +206,14 @@ class SortLastFrame:
             renderer.set_partition(0, n_instances)
             renderer.set_partition_interleaved(chunk, rank, world)
             renderer.set_shade_bands(band, rank, world)
+            if hasattr(renderer, "set_partition_replication"):
+                renderer.set_partition_replication(replicate_pixels)
             self.rows = band_row_index(height, band, rank, world)  # this rank's rows (host tensor)
             self._row_index = [band_row_index(height, band, k, world).to(vis_tensor.device) for k in range(world)]
         else:
             renderer.set_partition_interleaved(DEFAULT_CHUNK, 0, 1)
+            if hasattr(renderer, "set_partition_replication"):
+                renderer.set_partition_replication(0.0)
             renderer.set_partition(*instance_range(n_instances, rank, world))
             renderer.set_shade_rows(*row_range(height, rank, world))
             self.rows = torch.arange(*row_range(height, rank, world), dtype=torch.int64)

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("RDR_LIB_PATH") or os.path.join(_HERE, "librdr_hip.so"
 # every symbol include/rdr_abi.h declares
 ABI_SYMBOLS = [
     "rdr_create", "rdr_set_scene", "rdr_update_transforms", "rdr_render", "rdr_render_visbuffer", "rdr_shade",
-    "rdr_set_partition", "rdr_set_shade_rows", "rdr_set_partition_interleaved", "rdr_set_shade_bands", "rdr_visbuffer_device_ptr", "rdr_color_device_ptr",
+    "rdr_set_partition", "rdr_set_shade_rows", "rdr_set_partition_interleaved", "rdr_set_shade_bands", "rdr_set_partition_replication", "rdr_visbuffer_device_ptr", "rdr_color_device_ptr",
     "rdr_set_stream", "rdr_sync", "rdr_read_visbuffer", "rdr_read_visbuffer_u64", "rdr_read_color",
     "rdr_get_stats", "rdr_build_ubo", "rdr_get_ubo", "rdr_destroy", "rdr_last_error",
     "rdr_bake_brdf_lut", "rdr_bake_env_map", "rdr_mesh_build", "rdr_mesh_result", "rdr_mesh_free", "rdr_decode_bc",
@@ -55,6 +55,7 @@ def load_library():
     L.rdr_set_shade_rows.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.rdr_set_partition_interleaved.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
     L.rdr_set_shade_bands.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.rdr_set_partition_replication.argtypes = [vp, C.c_float]
     L.rdr_visbuffer_device_ptr.argtypes = [vp]
     L.rdr_visbuffer_device_ptr.restype = vp
     L.rdr_color_device_ptr.argtypes = [vp]
@@ -173,6 +174,11 @@ class Renderer:
     def set_partition_interleaved(self, chunk, rank, world):
         """Chunk j (``chunk`` meshlets) of draw d belongs to rank (j + d) % world."""
         self._check(self._L.rdr_set_partition_interleaved(self._h, chunk, rank, world))
+
+    def set_partition_replication(self, min_triangle_pixels):
+        """Draws whose triangles average more than this many pixels are drawn by every rank, large triangles on the
+        rank's own rows only (0 = off)."""
+        self._check(self._L.rdr_set_partition_replication(self._h, float(min_triangle_pixels)))
 
     def set_shade_bands(self, band, rank, world):
         """Bands of ``band`` rows dealt round-robin: band b is shaded by rank b % world."""

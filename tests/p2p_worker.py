@@ -39,6 +39,7 @@ def main():
     if os.environ.get("P2P_SPLIT", "interleaved") == "interleaved":  # chunks of meshlets and bands of rows dealt round-robin
         r.set_partition_interleaved(64, rank, world)
         r.set_shade_bands(32, rank, world)
+        r.set_partition_replication(float(os.environ.get("P2P_REPLICATE", "0")))  # > 0: near draws are taken by every rank
         mine = band_row_index(H, 32, rank, world).numpy()
     else:
         r.set_partition(*instance_range(scene.meshlet_visibility_count, rank, world))

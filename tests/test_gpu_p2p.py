@@ -35,7 +35,8 @@ def test_ranks_sharing_one_gpu_composite_to_the_single_gpu_frame(tmp_path, world
 
 @pytest.mark.parametrize("size,env", [("250x141", {}), ("251x139", {}), ("256x144", {"P2P_SKYBOX": "1"}),
                                       ("256x144", {"RDR_COMPOSITE_TILE_FLAGS": "0"}), ("256x144", {"P2P_OCCLUSION": "1"}),
-                                      ("251x139", {"P2P_SPLIT": "contiguous"})])
+                                      ("251x139", {"P2P_SPLIT": "contiguous"}), ("256x144", {"P2P_REPLICATE": "2.0"}),
+                                      ("640x360", {"P2P_REPLICATE": "8.0", "P2P_OCCLUSION": "1"})])
 def test_tile_skipping_at_awkward_sizes_with_skybox_and_switched_off(tmp_path, size, env):
     """The exchange moves 32x32-pixel tiles and skips those no rank touched: widths that are not a multiple of four
     (or odd), heights that cut tiles, a skybox (no pixel is clear colour: every tile travels), the flags off, and

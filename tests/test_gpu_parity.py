@@ -421,6 +421,50 @@ def test_interleaved_partitions_composite_to_full_frame(oracle, world, chunk):
     g.close()
 
 
+@pytest.mark.parametrize("world,size,occlusion", [(2, (320, 180), False), (3, (333, 187), False), (8, (256, 300), False), (3, (320, 180), True)])
+def test_draws_every_rank_takes_compose_to_the_full_frame(world, size, occlusion):
+    """rdr_set_partition_replication: the hall's few screen-filling triangles are drawn by every rank, each on the
+    rows it shades.  What the exchange reads of a rank's buffer are its own rows, so: the minimum over the ranks is
+    the full frame, every rank's own rows hold nothing the full frame does not, and the pixel work of the large
+    triangles is spread over the ranks instead of sitting with one."""
+    sc = synth.make_atrium()
+    w, h = size
+    conf = RendererConfig(cull_enabled=occlusion)
+    g = Renderer(w, h, conf)
+    g.set_scene(sc)
+    frames = 3 if occlusion else 1
+    for _ in range(frames):
+        g.render_visbuffer()
+    full = g.read_visbuffer_u64().copy()
+    frag = {}
+    for px in (0.0, 64.0):
+        acc = np.full_like(full, abi.VIS_CLEAR)
+        frag[px] = []
+        for rank in range(world):
+            g.set_partition_interleaved(64, rank, world)
+            g.set_shade_bands(32, rank, world)
+            g.set_partition_replication(px)
+            for _ in range(frames):
+                g.render_visbuffer()
+            assert g.frame_status() == 0
+            part = g.read_visbuffer_u64()
+            frag[px].append(g.stats()["fragments"])
+            mine = ((np.arange(h) // 32) % world) == rank
+            assert (part[mine] >= full[mine]).all()
+            if px > 0.0:  # the rank's own rows are complete for the draws every rank takes: the hall is one of them
+                assert (part[mine] != abi.VIS_CLEAR).all()
+            acc = np.minimum(acc, part)
+        assert np.array_equal(acc, full), px
+    if not occlusion:
+        assert max(frag[64.0]) / (sum(frag[64.0]) / world) < max(frag[0.0]) / (sum(frag[0.0]) / world)
+    # shading each rank's rows of its own composited buffer gives the single-GPU image (the shading passes find every
+    # draw's per-frame record whichever rank drew it)
+    g.set_partition_replication(0.0)
+    g.set_partition_interleaved(64, 0, 1)
+    g.set_shade_rows(0, h)
+    g.close()
+
+
 @pytest.mark.parametrize("world,band,size", [(2, 32, (320, 180)), (3, 32, (333, 187)), (8, 32, (256, 300)), (2, 64, (320, 180))])
 def test_shade_bands_compose_to_the_full_image(world, band, size):
     """Bands of rows dealt round-robin (rdr_set_shade_bands): a rank shades exactly its rows, and the ranks'
