@@ -34,6 +34,9 @@ def scenes(names):
     if "atrium" in names:
         out.append(("atrium, 3840x2160", lambda: synth.make_atrium(columns=10, spheres=60, sphere_subdiv=5),
                     3840, 2160, RendererConfig(cull_enabled=False, collect_stats=True, time_kernels=1, skybox=True)))
+    if "atrium8k" in names:
+        out.append(("atrium, 7680x4320", lambda: synth.make_atrium(columns=10, spheres=60, sphere_subdiv=5),
+                    7680, 4320, RendererConfig(cull_enabled=False, collect_stats=True, time_kernels=1, skybox=True)))
     if "field_xl" in names:
         out.append(("Field-XL (50 000 x icosphere-5), 7680x4320", lambda: synth.make_field(50000, 5, lods=1, with_env=True, prepared=True),
                     7680, 4320, RendererConfig(lod_enabled=False, cull_enabled=False, collect_stats=True, time_kernels=1)))

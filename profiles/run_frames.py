@@ -26,6 +26,11 @@ else:
     conf = RendererConfig(cull_enabled=os.environ.get("RDR_OCCLUSION", "0") != "0", collect_stats=True, time_kernels=True)
 r = Renderer(w, h, conf)
 r.set_scene(scene)
+if os.environ.get("RUN_WORLD"):  # one rank's share of a sort-last split, alone: RUN_WORLD=8 RUN_RANK=0 [RUN_REPLICATE=2048]
+    world, rank = int(os.environ["RUN_WORLD"]), int(os.environ.get("RUN_RANK", "0"))
+    r.set_partition_interleaved(64, rank, world)
+    r.set_shade_bands(32, rank, world)
+    r.set_partition_replication(float(os.environ.get("RUN_REPLICATE", "0")))
 for _ in range(frames):
     r.render()
 r.sync()

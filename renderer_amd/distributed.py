@@ -49,7 +49,11 @@ def row_range(height, rank, world):
 
 DEFAULT_CHUNK = 64  # meshlets per dealt chunk: one cull command
 DEFAULT_BAND = 32   # rows per dealt band: one tile row of the peer-to-peer exchange
-DEFAULT_REPLICATE_PIXELS = 2048.0  # draws whose triangles average more pixels than this are drawn by every rank, on its own rows
+# rdr_set_partition_replication's threshold (mean projected triangle area above which a draw is drawn by every rank,
+# on its own rows).  Off by default: at 3840x2160 it evens the ranks' geometry time out (interior scene, 8 ranks:
+# max / mean 1.45 -> 1.07) but does not shorten the slowest rank, because the tile path a rank then runs is a chain
+# of dependent steps of about 0.1 ms whatever its share of the pixels (profiles/r3/rank_alone_*.txt).
+DEFAULT_REPLICATE_PIXELS = 0.0
 
 
 def band_spans(height, band, rank, world):
