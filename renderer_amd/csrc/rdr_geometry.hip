@@ -458,13 +458,7 @@ RDR_DEV void emit_fragment(const FrameView& fv, int px, int py, float z, uint32_
     // The result is not used: the atomic is issued and forgotten, so a lane that produces
     // several fragments never waits for a round trip to the L2 (a pre-test load would cost
     // one per fragment).
-#if defined(RDR_EXP_ATOMICS) && RDR_EXP_ATOMICS == 1 // timing experiment: no atomic at all (wrong image)
-    if (key == 1ull) *p = key;
-#elif defined(RDR_EXP_ATOMICS) && RDR_EXP_ATOMICS == 2 // timing experiment: the atomic performed in the XCD's own L2 (wrong image)
-    __hip_atomic_fetch_min(p, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
     __hip_atomic_fetch_min(p, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
 }
 
 // (float)v for an edge-function value, correctly rounded like the plain conversion: below 2^53
@@ -1219,19 +1213,24 @@ RDR_DEV void clip_store(ClipLds& l, uint32_t lane, int buf, int i, const ClipVer
     for (int k = 0; k < 4; ++k) l.v[buf][i][4 + k][lane] = c.uv[k];
 }
 
+constexpr uint32_t kSetupChunk = 16;
 // One wave's share of the set-up: wave `wave_index` of `n_waves`, with an LDS polygon buffer of its own.
 RDR_DEV void tile_setup_role(const SceneView& sv, const FrameView& fv, ClipLds& clip, uint32_t wave_index, uint32_t n_waves) {
     const uint32_t lane = lane_id();
     const uint32_t count = min(fv.counters->deferred_count, fv.deferred_capacity);
     const float half_w = (float)fv.width * 0.5f, half_h = (float)fv.height * 0.5f;
-    const uint32_t stride = n_waves * 64u;
+    // A wave takes kSetupChunk triangles at a time, not 64: a record that covers many tiles is counted into its tiles
+    // by the whole wave (count_tiles), one such record after another, and the triangles that come here are mostly of
+    // that kind (walls, floors), so small chunks spread those walks over many more waves; the clipping in front of
+    // them is short by comparison.
+    const uint32_t stride = n_waves * kSetupChunk;
     // whole waves iterate together so that slots can be reserved with one atomic per wave
-    for (uint32_t base_i = wave_index * 64u; base_i < count; base_i += stride) {
+    for (uint32_t base_i = wave_index * kSetupChunk; base_i < count; base_i += stride) {
         const uint32_t di = base_i + lane;
         int n = 0, cur = 0; // vertex count and the buffer that holds the polygon
         bool cull_front = true, masked = false, alpha_draw = false, unclipped = false;
         uint32_t id = 0, draw_id = 0, replicated = 0;
-        if (di < count) {
+        if (lane < kSetupChunk && di < count) {
             const DeferredTriangle* dt = &fv.deferred[di];
             draw_id = dt->draw_id;
             id = dt->id;
