@@ -84,7 +84,7 @@ pub const RDR_FRAME_SHADOW_STACK: u32 = 64;
 pub const RDR_FRAME_PEER_TIMEOUT: u32 = 128;
 
 pub const RDR_COMPOSITE_MAX_RANKS: usize = 16;
-#[repr(C)] #[derive(Clone, Copy)] pub struct rdr_composite_handle { pub vis: [u8; 64], pub color: [u8; 64], pub ctrl: [u8; 64] }
+#[repr(C)] #[derive(Clone, Copy)] pub struct rdr_composite_handle { pub vis: [u8; 64], pub color: [u8; 64], pub ctrl: [u8; 64], pub info: [u8; 16] }
 
 #[repr(C)] pub struct rdr_renderer { _private: [u8; 0] }
 #[repr(C)] pub struct rdr_mesh_builder { _private: [u8; 0] }
@@ -141,5 +141,5 @@ const _: () = {
     assert!(std::mem::size_of::<rdr_mesh_draw>() == 16);
     assert!(std::mem::size_of::<rdr_material>() == 272);
     assert!(std::mem::size_of::<rdr_ubo>() == 288);
-    assert!(std::mem::size_of::<rdr_composite_handle>() == 192);
+    assert!(std::mem::size_of::<rdr_composite_handle>() == 208);
 };

@@ -397,11 +397,16 @@ typedef struct rdr_composite_handle { /* three hipIpcMemHandle_t: keys, image, c
     uint8_t vis[64];
     uint8_t color[64];
     uint8_t ctrl[64];
+    uint8_t info[16]; /* bytes 0..3: the exporting renderer's exchange counter (little endian); the rest zero */
 } rdr_composite_handle;
 /* This renderer's handles, to be sent to every other rank (any transport: a file, MPI, a socket). */
 int rdr_composite_export(rdr_renderer* r, rdr_composite_handle* out);
-/* handles[world]: every rank's export in rank order (handles[rank] is not read).  Collective in the
- * sense that every rank must connect before any rank's first exchange completes. */
+/* handles[world]: every rank's export in rank order.  Collective in the sense that every rank must connect
+ * before any rank's first exchange completes.  The ranks' exchange counters are aligned here (every rank
+ * continues from the largest counter among the handles), so renderers that ran different numbers of frames
+ * before (one was recreated, one failed a frame) meet in the same phase again.  After a failure while
+ * connected (a peer that did not arrive, a frame of this rank that dropped work) the connection is broken:
+ * exchange and gather fail until rdr_composite_disconnect, a new export and a new connect on every rank. */
 int rdr_composite_connect(rdr_renderer* r, uint32_t rank, uint32_t world, const rdr_composite_handle* handles);
 int rdr_composite_exchange(rdr_renderer* r);
 int rdr_composite_gather(rdr_renderer* r);

@@ -552,6 +552,7 @@ int check_finished_frames(rdr_renderer* r, const char* who) {
         }
     }
     if (bad) {
+        rdr_composite_mark_broken(r->composite); // this rank stops here while its peers go on: the phases part
         rdr_set_error(std::string(who) + ": an earlier frame dropped work (" + status_message(bad) + " overflowed); its image is incomplete");
         return 1;
     }
@@ -1027,9 +1028,15 @@ int rdr_composite_disconnect(rdr_renderer* r) {
     if (!r->composite) return 0;
     RDR_HIP(hipSetDevice(r->device));
     RDR_HIP(hipStreamSynchronize(r->stream));
-    const int rc = rdr_composite_check(r->composite, "rdr_composite_disconnect");
+    // a wait that gave up and has not been reported yet is reported here; a connection already known to be broken
+    // (the caller has seen that error) closes without another one
+    const bool unreported_timeout = rdr_composite_timed_out(r->composite);
     rdr_composite_close(r->composite);
-    return rc;
+    if (unreported_timeout) {
+        rdr_set_error("rdr_composite_disconnect: a peer rank did not reach the last exchange within 5 s (that frame's image is not valid)");
+        return 1;
+    }
+    return 0;
 }
 
 int rdr_frame_status(rdr_renderer* r, uint32_t* flags) {

@@ -308,6 +308,13 @@ extern "C" int rdr_decode_bc_noalloc(int device, uint32_t format, uint32_t width
     RDR_CHECK(need <= kBcScratchBlocks && padded * 4 <= kBcScratchTexels,
               "decode_bc_noalloc: mip chain larger than the built-in staging memory (1.5 MiB of blocks, 6 MiB of "
               "decoded texels: up to a full 1024 x 1024 chain); use rdr_decode_bc");
+    struct DeviceRestore { // the caller's current device is put back on every return path
+        int previous = -1;
+        ~DeviceRestore() {
+            if (previous >= 0) (void)hipSetDevice(previous);
+        }
+    } restore;
+    if (hipGetDevice(&restore.previous) != hipSuccess) restore.previous = -1;
     RDR_HIP(hipSetDevice(device));
     uint8_t* base = nullptr;
     if (scratch_on_device(device, &base)) return 1;

@@ -190,6 +190,7 @@ struct rdr_composite_state {
     volatile uint32_t* timed_out = nullptr; // pinned host word
     uint32_t* timed_out_dev = nullptr;
     bool connected = false;
+    bool broken = false; // a wait timed out or a frame of this rank failed while connected: the ranks' phases may differ
     // tiles: per tile of the frame, did any rank touch it this frame / the last time this rank pushed its rows
     uint32_t width = 0, height = 0;
     uint32_t* union_now = nullptr;
@@ -252,6 +253,8 @@ void rdr_composite_close(rdr_composite_state* c) {
         c->opened[p][0] = c->opened[p][1] = c->opened[p][2] = false;
     }
     c->connected = false;
+    c->broken = false;
+    if (c->timed_out) *c->timed_out = 0;
     if (c->union_now) (void)hipFree(c->union_now);
     if (c->union_prev) (void)hipFree(c->union_prev);
     c->union_now = c->union_prev = nullptr;
@@ -274,6 +277,8 @@ int rdr_composite_export_handles(rdr_composite_state* c, void* vis, void* color,
     std::memcpy(out->color, &h, 64);
     RDR_HIP(hipIpcGetMemHandle(&h, c->ctrl));
     std::memcpy(out->ctrl, &h, 64);
+    std::memset(out->info, 0, sizeof(out->info));
+    std::memcpy(out->info, &c->frame, 4); // where this renderer's phase numbers stand (aligned across the ranks at connect)
     return 0;
 }
 
@@ -283,7 +288,17 @@ int rdr_composite_open(rdr_composite_state* c, uint32_t rank, uint32_t world, co
                        uint32_t width, uint32_t height) {
     RDR_CHECK(world >= 1 && world <= RDR_COMPOSITE_MAX_RANKS && rank < world, "rdr_composite_connect: rank / world out of range (at most 16 ranks)");
     RDR_CHECK(!c->connected, "rdr_composite_connect: already connected");
-    c->rank = rank; c->world = world; // the frame number keeps counting across connections: phases only ever grow
+    c->rank = rank; c->world = world;
+    // Phase numbers only ever grow, and every rank continues from the same one: the largest exchange counter among
+    // the handles (this rank's own included).  Whatever an earlier connection left in a control block is smaller than
+    // the first phase of this one, so a stale word cannot satisfy a wait.
+    for (uint32_t p = 0; p < world; ++p) {
+        uint32_t theirs = 0;
+        std::memcpy(&theirs, handles[p].info, 4);
+        if (p != rank && (int32_t)(theirs - c->frame) > 0) c->frame = theirs;
+    }
+    c->broken = false;
+    *c->timed_out = 0;
     c->width = width; c->height = height;
     const size_t npx = (size_t)width * height, words = rdr_touched_words(width, height);
     RDR_HIP(hipMalloc(reinterpret_cast<void**>(&c->union_now), words * 4));
@@ -318,10 +333,21 @@ int rdr_composite_open(rdr_composite_state* c, uint32_t rank, uint32_t world, co
 
 bool rdr_composite_timed_out(const rdr_composite_state* c) { return c && *c->timed_out != 0; }
 
+void rdr_composite_mark_broken(rdr_composite_state* c) {
+    if (c && c->connected) c->broken = true;
+}
+
 int rdr_composite_check(rdr_composite_state* c, const char* who) {
     if (*c->timed_out) {
         *c->timed_out = 0;
-        rdr_set_error(std::string(who) + ": a peer rank did not reach the exchange within 5 s (the frame's image is not valid)");
+        c->broken = c->connected;
+        rdr_set_error(std::string(who) + ": a peer rank did not reach the exchange within 5 s (the frame's image is not valid); "
+                      "disconnect and connect again on every rank");
+        return 1;
+    }
+    if (c->broken) {
+        rdr_set_error(std::string(who) + ": the exchange is out of step with the other ranks after an earlier failure; "
+                      "disconnect and connect again on every rank");
         return 1;
     }
     return 0;

@@ -501,6 +501,7 @@ int rdr_composite_open(rdr_composite_state* c, uint32_t rank, uint32_t world, co
                        uint32_t width, uint32_t height);
 bool rdr_composite_connected(const rdr_composite_state* c);
 int rdr_composite_check(rdr_composite_state* c, const char* who);
+void rdr_composite_mark_broken(rdr_composite_state* c); // a frame of this rank failed while connected
 bool rdr_composite_timed_out(const rdr_composite_state* c); // a bounded wait gave up (not cleared by asking)
 // The rows a rank composites and pushes: [row_lo, row_hi), or (band_world > 1) its bands of (1 << band_shift) rows.
 struct RowSet {

@@ -185,10 +185,10 @@ class Renderer:
         self._check(self._L.rdr_set_shade_bands(self._h, band, rank, world))
 
     # --- peer-to-peer sort-last exchange (one process per GPU) -------------------------
-    COMPOSITE_HANDLE_BYTES = 192
+    COMPOSITE_HANDLE_BYTES = 208
 
     def composite_export(self):
-        """This renderer's IPC handles (192 bytes) for the other ranks."""
+        """This renderer's IPC handles and exchange counter (208 bytes) for the other ranks."""
         buf = C.create_string_buffer(self.COMPOSITE_HANDLE_BYTES)
         self._check(self._L.rdr_composite_export(self._h, buf))
         return buf.raw

@@ -80,6 +80,67 @@ def main():
         r.close()
         raise SystemExit(0 if ok else 1)
 
+    if os.environ.get("P2P_MODE") == "reconnect":
+        # Rank 1 sits out one frame (as a rank whose frame failed would): rank 0's exchange gives up after its bounded
+        # wait, its connection is broken from then on, and both ranks disconnect, export and connect again.  The two
+        # renderers have then run different numbers of exchanges; the connect aligns them, and the frames that follow
+        # must composite exactly.
+        from renderer_amd import RendererError, abi
+        ok = True
+
+        def frame():
+            r.render_visbuffer()
+            r.composite_exchange()
+            r.shade()
+            r.composite_gather()
+            r.sync()
+
+        frame()  # both ranks
+        if rank == 0:
+            try:
+                frame()  # alone: the wait for rank 1 times out
+                ok = bool(r.frame_status() & abi.FRAME_PEER_TIMEOUT)
+                try:
+                    r.composite_exchange()
+                    ok = False
+                except RendererError as e:
+                    ok = ok and ("peer rank" in str(e) or "out of step" in str(e))
+                try:
+                    r.render_visbuffer()
+                    r.composite_exchange()  # still broken after the error was reported once
+                    ok = False
+                except RendererError as e:
+                    ok = ok and "out of step" in str(e)
+            except RendererError as e:
+                ok = "peer rank" in str(e)
+        publish(os.path.join(d, f"phase1_{rank}"), b"1")
+        wait_for([os.path.join(d, f"phase1_{k}") for k in range(world)], 90.0)
+        try:
+            r.composite_disconnect()
+        except RendererError:
+            pass
+        publish(os.path.join(d, f"handle2_{rank}.bin"), r.composite_export())
+        names = [os.path.join(d, f"handle2_{k}.bin") for k in range(world)]
+        wait_for(names)
+        r.composite_connect(rank, world, [open(n, "rb").read() for n in names])
+        whole = Renderer(W, H, conf, device=device)
+        whole.set_scene(scene)
+        whole.render()
+        vis, color = whole.read_visbuffer_u64(), whole.read_color()
+        for k in range(3):
+            frame()
+            gv, gc = r.read_visbuffer_u64(), r.read_color()
+            if not (np.array_equal(gv[mine], vis[mine]) and np.array_equal(gc, color)):
+                print(f"rank {rank}: frame {k} after the reconnect differs", flush=True)
+                ok = False
+            publish(os.path.join(d, f"re_{k}_{rank}"), b"1")
+            wait_for([os.path.join(d, f"re_{k}_{q}") for q in range(world)])
+        r.composite_disconnect()
+        r.close()
+        whole.close()
+        print(f"rank {rank}: {'ok' if ok else 'MISMATCH'}", flush=True)
+        raise SystemExit(0 if ok else 1)
+
     whole = Renderer(W, H, conf, device=device)  # the single-GPU answer, in this process
     whole.set_scene(scene)
     base = scene.camera

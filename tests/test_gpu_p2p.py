@@ -49,3 +49,11 @@ def test_a_peer_that_never_arrives_is_an_error_not_a_hang(tmp_path):
     about five seconds, reports RDR_FRAME_PEER_TIMEOUT and fails its next exchange call."""
     outs = _run_ranks(tmp_path, 2, P2P_MODE="timeout")
     assert "rank 0: waited" in outs[0]
+
+
+def test_ranks_out_of_step_meet_again_after_a_reconnect(tmp_path):
+    """A rank that sat out a frame leaves the ranks' exchange counters apart.  The rank that waited gets an error, its
+    connection stays broken (no silent reads of half-written keys), and after disconnect + export + connect on both
+    ranks the counters are aligned and frames composite exactly again."""
+    outs = _run_ranks(tmp_path, 2, P2P_MODE="reconnect")
+    assert all("ok" in o for o in outs), outs
