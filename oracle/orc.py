@@ -37,6 +37,8 @@ def lib():
         L.orc_resolve.argtypes = [C.POINTER(abi.SceneDesc), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_shade.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.Ubo), C.c_void_p, C.c_void_p, C.c_uint32,
                                 C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_shade_quad_lod.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.Ubo), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.POINTER(C.c_uint64)]
         L.orc_skybox.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.Ubo), C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_bake_brdf_lut.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_bake_env_map.argtypes = [C.POINTER(abi.CubemapDesc), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -109,6 +111,17 @@ class OracleRenderer:
                 rc = lib().orc_skybox(C.byref(self.desc), C.byref(self.ubo), vis.ctypes.data, lo, hi, out.ctypes.data)
                 assert rc == 0
         return (out, lin) if want_linear else out
+
+    def shade_quad_lod(self):
+        """(image, level per pixel, undefined count): the frame with texture(lambertian, n) at the level of detail a
+        2 x 2-quad-difference implementation would use instead of level 0."""
+        out = np.zeros((self.height, self.width, 4), np.uint8)
+        lod = np.zeros((self.height, self.width), np.float32)
+        undefined = C.c_uint64(0)
+        rc = lib().orc_shade_quad_lod(C.byref(self.desc), C.byref(self.ubo), self.vis.ctypes.data, self.draw_lod.ctypes.data,
+                                      out.ctypes.data, lod.ctypes.data, C.byref(undefined))
+        assert rc == 0
+        return out, lod, int(undefined.value)
 
     def render(self, camera=None, sun=None):
         self.render_visbuffer(camera, sun)

@@ -417,6 +417,11 @@ typedef struct {
     rdr_cubemap_desc lambertian, ggx, charlie;
 } env_ctx;
 
+/* Debug state of orc_shade_quad_lod (below): the level of detail to take the Lambertian tap at instead of 0, and
+ * where shade_pixel leaves the direction it takes that tap with. */
+static _Thread_local float dbg_lambert_lod = 0.0f;
+static _Thread_local v3 dbg_lambert_dir;
+
 static v4 brdf_lut_tap(const env_ctx* e, float x, float y) {
     return orc_image_sample_lod(&e->lut, clampf(x, 0.0f, 1.0f), clampf(y, 0.0f, 1.0f), 0.0f);
 }
@@ -435,7 +440,8 @@ static v3 ibl_ggx(const env_ctx* e, v3 n, v3 v, float ndv, float rough, v3 refl0
 
 static v3 ibl_lambertian(const env_ctx* e, float ndv, v3 n, float rough, v3 diffuse, v3 f0, float spec_w) {
     v4 fab = brdf_lut_tap(e, ndv, rough);
-    v4 ir = orc_cube_sample_lod(&e->lambertian, n, 0.0f);
+    v4 ir = orc_cube_sample_lod(&e->lambertian, n, dbg_lambert_lod); /* 0 outside orc_shade_quad_lod */
+    dbg_lambert_dir = n;
     v3 irr = v3_make(ir.x, ir.y, ir.z);
     v3 fr = v3_sub(v3_make(fmaxf(1.0f - rough, f0.x), fmaxf(1.0f - rough, f0.y), fmaxf(1.0f - rough, f0.z)), f0);
     v3 ks = v3_add(f0, v3_scale(fr, pow5(1.0f - ndv)));
@@ -702,6 +708,125 @@ int orc_shade(const rdr_scene_desc* s, const rdr_ubo* u, const uint64_t* vis, co
         }
     }
     shadow_scene_free(&ss);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* How much does taking texture(lambertian, n) at level 0 cost?        */
+/* ------------------------------------------------------------------ */
+/* shading.frag.glsl:231 samples the irradiance map with an implicit level of detail, which a Vulkan
+ * implementation derives from the differences of the coordinate inside each 2 x 2 pixel quad; this restatement
+ * (and the kernels) take level 0.  The other implicit-LOD taps need no such question: the BRDF table has one
+ * level (bake/src/brdf.rs:59-65 writes num_levels = 1), and the GGX / Charlie taps state their level.
+ * This function shades the frame twice: once as orc_shade does, recording the tap's direction per pixel, and once
+ * with the level a quad-difference implementation would use: per quad, d/dx from the two pixels of a row and
+ * d/dy from the two pixels of a column, transformed to the selected face's coordinates as the specification's
+ * "cube map derivative transformation" has it, rho = the longer of the two footprint axes in texels of level 0,
+ * level = log2(rho) clamped to the chain.  A quad with an uncovered pixel has no defined differences (the shader
+ * has returned there, shading.frag.glsl:324-326): such pixels keep level 0 and are counted in *undefined.
+ * out_lod (W*H floats, may be NULL) receives the level used. */
+static void cube_face_map(int face, v3 d, float* sc, float* tc, float* ma) {
+    switch (face) {
+    case 0: *sc = -d.z; *tc = -d.y; *ma = d.x; break;
+    case 1: *sc = d.z; *tc = -d.y; *ma = -d.x; break;
+    case 2: *sc = d.x; *tc = d.z; *ma = d.y; break;
+    case 3: *sc = d.x; *tc = -d.z; *ma = -d.y; break;
+    case 4: *sc = d.x; *tc = -d.y; *ma = d.z; break;
+    default: *sc = -d.x; *tc = -d.y; *ma = -d.z; break;
+    }
+}
+
+int orc_shade_quad_lod(const rdr_scene_desc* s, const rdr_ubo* u, const uint64_t* vis, const uint8_t* draw_lod,
+                       uint8_t* out_rgba8, float* out_lod, uint64_t* undefined) {
+    int W = (int)u->screen_width, H = (int)u->screen_height;
+    size_t npx = (size_t)W * H;
+    float* dirs = (float*)malloc(npx * 3 * sizeof(float));
+    float* lods = (float*)calloc(npx, sizeof(float));
+    if (!dirs || !lods) { free(dirs); free(lods); return 1; }
+    orc_srgb_lut_init();
+    env_ctx env;
+    env_setup(&env, s);
+    shadow_scene ss;
+    shadow_scene_build(&ss, s);
+    uint64_t undef = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int iy = 0; iy < H; ++iy) {
+            for (int ix = 0; ix < W; ++ix) {
+                size_t pi = (size_t)iy * W + ix;
+                uint64_t key = vis[pi];
+                uint8_t* o8 = out_rgba8 + pi * 4;
+                if (key == RDR_VIS_CLEAR) {
+                    o8[0] = o8[1] = o8[2] = o8[3] = 0;
+                    continue;
+                }
+                uint32_t id = (uint32_t)key, instance = id >> 7, tri = id & 127u;
+                uint32_t lo = 0, hi = s->draw_count;
+                while (hi - lo > 1) {
+                    uint32_t mid = (lo + hi) / 2;
+                    if (s->mesh_draws[mid].meshlet_visibility_offset <= instance) lo = mid; else hi = mid;
+                }
+                const rdr_mesh_draw* d = &s->mesh_draws[lo];
+                const rdr_mesh_lod* Ld = &s->meshes[d->mesh_index].lods[draw_lod[lo]];
+                uint32_t meshlet = Ld->meshlet_offset + (instance - d->meshlet_visibility_offset);
+                float uvx = ((float)ix + 0.5f) * (1.0f / (float)W);
+                float uvy = 1.0f - ((float)iy + 0.5f) * (1.0f / (float)H);
+                dbg_lambert_lod = pass ? lods[pi] : 0.0f;
+                v3 c = shade_pixel(s, u, &env, &ss, lo, meshlet, tri, uvx, uvy);
+                dbg_lambert_lod = 0.0f;
+                if (!pass) { dirs[pi * 3] = dbg_lambert_dir.x; dirs[pi * 3 + 1] = dbg_lambert_dir.y; dirs[pi * 3 + 2] = dbg_lambert_dir.z; }
+                o8[0] = srgb_encode(c.x); o8[1] = srgb_encode(c.y); o8[2] = srgb_encode(c.z); o8[3] = 255;
+            }
+        }
+        if (pass) break;
+        /* the level per 2 x 2 quad (quads are aligned to even pixel coordinates) */
+        const float n0 = (float)env.lambertian.size, max_lod = (float)(env.lambertian.mip_count - 1);
+        for (int qy = 0; qy < H; qy += 2) {
+            for (int qx = 0; qx < W; qx += 2) {
+                int whole = qx + 1 < W && qy + 1 < H;
+                for (int k = 0; k < 4 && whole; ++k)
+                    whole = vis[(size_t)(qy + (k >> 1)) * W + qx + (k & 1)] != RDR_VIS_CLEAR;
+                if (!whole) {
+                    for (int k = 0; k < 4; ++k) {
+                        int x = qx + (k & 1), y = qy + (k >> 1);
+                        if (x < W && y < H && vis[(size_t)y * W + x] != RDR_VIS_CLEAR) undef++;
+                    }
+                    continue;
+                }
+                for (int k = 0; k < 4; ++k) {
+                    int x = qx + (k & 1), y = qy + (k >> 1);
+                    size_t p = (size_t)y * W + x;
+                    const float* a = dirs + p * 3;
+                    const float* bx = dirs + ((size_t)y * W + (qx + 1)) * 3; /* the row's right pixel minus its left */
+                    const float* ax = dirs + ((size_t)y * W + qx) * 3;
+                    const float* by = dirs + ((size_t)(qy + 1) * W + x) * 3; /* the column's lower pixel minus its upper */
+                    const float* ay = dirs + ((size_t)qy * W + x) * 3;
+                    v3 dv = v3_make(a[0], a[1], a[2]);
+                    v3 ddx = v3_make(bx[0] - ax[0], bx[1] - ax[1], bx[2] - ax[2]);
+                    v3 ddy = v3_make(by[0] - ay[0], by[1] - ay[1], by[2] - ay[2]);
+                    float sc, tc, ma;
+                    int face = cube_face(dv, &sc, &tc, &ma);
+                    float scx, tcx, max_, scy, tcy, may;
+                    cube_face_map(face, dv, &sc, &tc, &ma);
+                    cube_face_map(face, ddx, &scx, &tcx, &max_);
+                    cube_face_map(face, ddy, &scy, &tcy, &may);
+                    float inv = 1.0f / (ma * ma);
+                    float dsdx = 0.5f * (scx * ma - sc * max_) * inv, dtdx = 0.5f * (tcx * ma - tc * max_) * inv;
+                    float dsdy = 0.5f * (scy * ma - sc * may) * inv, dtdy = 0.5f * (tcy * ma - tc * may) * inv;
+                    float rx = sqrtf(dsdx * dsdx + dtdx * dtdx) * n0, ry = sqrtf(dsdy * dsdy + dtdy * dtdy) * n0;
+                    float rho = fmaxf(rx, ry);
+                    float lod = rho > 0.0f ? log2f(rho) : 0.0f;
+                    if (!(lod > 0.0f)) lod = 0.0f;
+                    if (lod > max_lod) lod = max_lod;
+                    lods[p] = lod;
+                }
+            }
+        }
+    }
+    if (out_lod) memcpy(out_lod, lods, npx * sizeof(float));
+    if (undefined) *undefined = undef;
+    shadow_scene_free(&ss);
+    free(dirs); free(lods);
     return 0;
 }
 

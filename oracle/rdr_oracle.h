@@ -41,6 +41,12 @@ int orc_shade(const rdr_scene_desc* scene, const rdr_ubo* ubo, const uint64_t* v
 /* Block-compressed mip chain (RDR_FORMAT_BC1..BC7_SRGB) -> tightly packed RGBA8 levels. */
 int orc_decode_bc(uint32_t format, uint32_t width, uint32_t height, uint32_t mip_count, const void* blocks, void* out_rgba8);
 
+/* Debug: the frame shaded with texture(lambertian, n) taken at the level of detail a 2 x 2-quad-difference
+ * implementation would use instead of level 0 (see orc_shade.c).  *undefined counts covered pixels whose quad has an
+ * uncovered pixel (no defined differences: they keep level 0). */
+int orc_shade_quad_lod(const rdr_scene_desc* scene, const rdr_ubo* ubo, const uint64_t* vis, const uint8_t* draw_lod,
+                       uint8_t* out_rgba8, float* out_lod, uint64_t* undefined);
+
 /* Skybox pass: fills the pixels of rows [row_lo, row_hi) whose key is the clear
  * value from env.skybox (no-op without one).  Run after orc_shade. */
 int orc_skybox(const rdr_scene_desc* scene, const rdr_ubo* ubo, const uint64_t* vis,
