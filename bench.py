@@ -300,7 +300,7 @@ def main():
             ab_dom, t_dom = ab[dom], kms[dom]
         achieved = ab_dom / (t_dom * 1e-3) / 1e9 if t_dom > 0 else 0.0
         # HBM traffic and vector-issue figures of the dominant kernel are NOT measured by this run (counters need
-        # rocprofv3 passes of their own): they are read from the committed record of profiles/refresh_r2.sh on the
+        # rocprofv3 passes of their own): they are read from the committed record of profiles/refresh_r3.sh on the
         # same workload, and the line says so (traffic_source)
         traffic = None
         issue = None
@@ -314,7 +314,7 @@ def main():
                     traffic = rec.get("kernels", {}).get(dom)
                     issue = rec.get("issue", {}).get(dom)
                     raster_issue = rec.get("issue", {}).get("raster")
-                    traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of profiles/refresh_r2.sh, committed; not this run)"
+                    traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of profiles/refresh_r3.sh, committed; not this run)"
             except Exception:
                 traffic = None
         out = {
@@ -385,10 +385,12 @@ def main():
                 if peak > 0:
                     out["raster_atomics"].update({"peak": peak, "frac": st["fragments"] / raster_s / peak, "unit": "atomics/s",
                                                   "peak_source": "profiles/atomic_peak.hip, pattern box_2x2_region32, measured in this run"})
-                    # which of its two limits the rasteriser is closer to
-                    issue_frac = (raster_issue or {}).get("valu_busy")  # share of the vector issue slots k_raster uses (committed PMC record)
-                    out["raster_atomics"]["closer_to"] = ("vector issue" if issue_frac is not None and issue_frac > out["raster_atomics"]["frac"]
-                                                          else "atomic rate" if issue_frac is not None else None)
+                    # its two throughput limits side by side (share of the atomic ceiling, share of the vector issue slots from
+                    # the committed PMC record); neither is what sets the kernel's length on this workload: a build without the
+                    # atomic runs no faster (profiles/r3/raster_without_atomics.txt), the kernel is a chain of LDS and memory
+                    # round trips per meshlet with five waves per SIMD to hide it
+                    out["raster_atomics"]["valu_issue_frac"] = (raster_issue or {}).get("valu_busy")
+                    out["raster_atomics"]["limits"] = "latency per meshlet first; of the throughput limits the atomic rate is the nearer one"
             except Exception as e:  # the helper library is optional
                 out["raster_atomics"]["peak_error"] = str(e)
         if world == 1 and frame is None and args.secondary_frames > 0:
