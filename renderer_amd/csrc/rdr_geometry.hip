@@ -1153,6 +1153,37 @@ RDR_DEV bool tile_touched(const FrameView& fv, const SetupTri& t, uint32_t tx, u
            edge_max(e20, kTile - 1, kTile - 1) + e20.bias >= 0;
 }
 
+// tile_touched for the tiles of one tile row, left to right: the three edge maxima are linear in the tile's position,
+// so after the first tile of the row each further one is three 64-bit additions and a sign test instead of three
+// edge set-ups (records that span the screen are counted and binned tile by tile, and those set-ups were most of it).
+// The caller walks tiles inside the record's own tile box, which is tile_touched's box test.
+struct TileRowWalk {
+    long long v[3];    // edge maximum over the current tile, top-left bias included: the tile is touched when none is negative
+    long long step[3]; // change per tile in x
+};
+RDR_DEV TileRowWalk tile_row_walk(const SetupTri& t, uint32_t tx0, uint32_t ty) {
+    const int x0 = (int)tx0 * kTile, y0 = (int)ty * kTile;
+    const EdgeEq e[3] = {make_edge(t.X0, t.Y0, t.X1, t.Y1, x0, y0), make_edge(t.X1, t.Y1, t.X2, t.Y2, x0, y0), make_edge(t.X2, t.Y2, t.X0, t.Y0, x0, y0)};
+    TileRowWalk r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        r.v[k] = edge_max(e[k], kTile - 1, kTile - 1) + e[k].bias;
+        r.step[k] = e[k].ax * kTile;
+    }
+    return r;
+}
+RDR_DEV bool tile_row_touched(const TileRowWalk& r) { return (r.v[0] | r.v[1] | r.v[2]) >= 0; }
+RDR_DEV void tile_row_next(TileRowWalk& r) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r.v[k] += r.step[k];
+}
+// Does this rank rasterise the record on the rows of tile row ty?  (Always, unless the record belongs to a draw every
+// sort-last rank draws: those are rasterised on the rank's own rows only.)
+RDR_DEV bool tile_row_wanted(const FrameView& fv, const SetupTri& t, uint32_t ty) {
+    const int y0 = (int)ty * kTile;
+    return !(t.masked & 4u) || rdr_rows_owned(fv, (uint32_t)max(y0, (int)t.py0), (uint32_t)min(y0 + kTile - 1, (int)t.py1));
+}
+
 // Binning of the set-up records into 64x64 tiles, two passes over the (record, tile) pairs where the record may
 // cover a pixel of the tile.  Counting happens where the records are made: the wave of k_tile_setup that produced
 // a record adds it to its tiles' counts (count_tiles).  k_tile_fill then turns the counts into bin offsets and
@@ -1183,10 +1214,14 @@ RDR_DEV void count_tiles(const FrameView& fv, const SetupTri& t, bool valid, uin
         w.px0 = (uint16_t)lo; w.py0 = (uint16_t)(lo >> 16); w.px1 = (uint16_t)hi; w.py1 = (uint16_t)(hi >> 16);
         w.masked = __shfl(t.masked, src, 64);
         const uint32_t wx0 = w.px0 / kTile, wy0 = w.py0 / kTile, ww = w.px1 / kTile - wx0 + 1u;
-        const uint32_t wn = ww * (w.py1 / kTile - wy0 + 1u);
-        for (uint32_t q = lane; q < wn; q += 64u) {
-            const uint32_t tx = wx0 + q % ww, ty = wy0 + q / ww;
-            if (tile_touched(fv, w, tx, ty)) atomicAdd(&fv.tile_count[ty * fv.tiles_x + tx], 1u);
+        const uint32_t rows = w.py1 / kTile - wy0 + 1u;
+        for (uint32_t row = lane; row < rows; row += 64u) { // a lane per tile row, walked left to right
+            const uint32_t ty = wy0 + row;
+            if (!tile_row_wanted(fv, w, ty)) continue;
+            TileRowWalk r = tile_row_walk(w, wx0, ty);
+            uint32_t* cnt = &fv.tile_count[ty * fv.tiles_x + wx0];
+            for (uint32_t i = 0; i < ww; ++i, tile_row_next(r))
+                if (tile_row_touched(r)) atomicAdd(cnt + i, 1u);
         }
     }
 }
@@ -1425,26 +1460,31 @@ RDR_DEV void tile_fill_role(const FrameView& fv, uint32_t block, uint32_t n_bloc
             const uint32_t record = base_i + (uint32_t)src;
             const SetupTri w = fv.setup[record]; // the same address in every lane: one broadcast load
             const uint32_t wx0 = w.px0 / kTile, wy0 = w.py0 / kTile, ww = w.px1 / kTile - wx0 + 1u;
-            const uint32_t wn = ww * (w.py1 / kTile - wy0 + 1u);
-            // four tiles per lane and round: the atomics return a value (the slot), and one round
-            // trip per 64 tiles was most of this kernel's length on records that span the screen
-            for (uint32_t q0 = lane; q0 < wn; q0 += 256u) {
-                bool touched[4];
-                uint32_t tiles[4], got[4];
+            const uint32_t rows = w.py1 / kTile - wy0 + 1u;
+            // a lane per tile row, eight tiles per round: the atomics return a value (the slot), and it is the round
+            // trips, not the tests, that a record spanning the screen pays for, so eight are in flight per lane
+            constexpr int kPerRound = 8;
+            for (uint32_t row = lane; row < rows; row += 64u) {
+                const uint32_t ty = wy0 + row;
+                if (!tile_row_wanted(fv, w, ty)) continue;
+                TileRowWalk r = tile_row_walk(w, wx0, ty);
+                const uint32_t tile0 = ty * fv.tiles_x + wx0;
+                for (uint32_t i0 = 0; i0 < ww; i0 += kPerRound) {
+                    bool touched[kPerRound];
+                    uint32_t got[kPerRound];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t q = q0 + 64u * k;
-                    const uint32_t tx = wx0 + q % ww, ty = wy0 + q / ww;
-                    touched[k] = q < wn && tile_touched(fv, w, tx, ty);
-                    tiles[k] = ty * fv.tiles_x + tx;
-                }
+                    for (int k = 0; k < kPerRound; ++k) {
+                        touched[k] = i0 + k < ww && tile_row_touched(r);
+                        tile_row_next(r);
+                    }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) got[k] = touched[k] ? atomicAdd(&fv.tile_cursor[tiles[k]], 1u) : 0u;
+                    for (int k = 0; k < kPerRound; ++k) got[k] = touched[k] ? atomicAdd(&fv.tile_cursor[tile0 + i0 + k], 1u) : 0u;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (!touched[k]) continue;
-                    const uint32_t slot = tile_off[tiles[k]] + got[k];
-                    if (slot < fv.bin_capacity) fv.bin_entries[slot] = record;
+                    for (int k = 0; k < kPerRound; ++k) {
+                        if (!touched[k]) continue;
+                        const uint32_t slot = tile_off[tile0 + i0 + k] + got[k];
+                        if (slot < fv.bin_capacity) fv.bin_entries[slot] = record;
+                    }
                 }
             }
         }
