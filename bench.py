@@ -348,9 +348,10 @@ def main():
             "kernel_ms_frames": st["frames_timed"], "kernel_ms_every": bracket_every,
             "kernel_ms_sum": round(sum(kms.values()), 4),
             "frame_minus_kernels_ms": round(ms - sum(kms.values()), 4),
-            "launches_per_frame": {"all_opaque_no_occlusion": 10, "with_alpha_tested_draws": 12,
-                                   "note": "dependent kernel launches of one frame on this path (draw cull, meshlet cull, raster, tile set-up, "
-                                           "mid + fill, tile raster, classify, shadow, shadow walk, shade; alpha-tested draws add two)"},
+            "launches_per_frame": {"all_opaque_no_occlusion": 8, "with_large_triangles": 10, "with_alpha_tested_draws": 12,
+                                   "note": "dependent kernel launches of one frame on this path (draw cull, meshlet cull, raster, tile path, "
+                                           "classify, shadow, shadow walk, shade; the tile path is one launch after a frame without large or "
+                                           "mid-sized triangles, else tile set-up, mid + fill, tile raster; alpha-tested draws add two)"},
             "frame_counters": {k: st[k] for k in ("draws_visible", "meshlets_tested", "meshlets_visible",
                                                   "triangles_submitted", "triangles_tested", "triangles_rasterised",
                                                   "fragments", "pixels_covered", "vertices_transformed")},
