@@ -1,0 +1,10 @@
+# scratch experiment runner (GPU box): parity first, then kernel times of the library variants
+set -e
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out
+cd $R
+timeout -k 10 400 python3 -u -m pytest tests/test_gpu_parity.py tests/test_ref_raster.py tests/test_gpu_tile_path.py -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/exp_tests.log 2>&1 || { tail -30 gpurun_out/exp_tests.log; exit 1; }
+tail -3 gpurun_out/exp_tests.log
+for scene in field fieldxl atrium alphafield; do
+  bash profiles/sweep_lib.sh "$LIBS" $scene 24
+done

@@ -96,6 +96,9 @@ struct rdr_renderer {
     DeviceBuffer<rdr_vertex> vertices;
     DeviceBuffer<float> pos_x, pos_y, pos_z;
     DeviceBuffer<float4> uv_sets;
+    DeviceBuffer<float> mpos_x, mpos_y, mpos_z; // positions and uv sets in meshlet_vertices order (SceneView::mpos_x)
+    DeviceBuffer<float4> muv;
+    bool meshlet_order = false;                 // those four are valid
     DeviceBuffer<uint32_t> meshlet_vertices;
     DeviceBuffer<uint8_t> meshlet_triangles;
     DeviceBuffer<rdr_meshlet> meshlets;
@@ -698,6 +701,34 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
         if (s.meshlet_triangle_bytes) std::memcpy(tri.data(), s.meshlet_triangles, s.meshlet_triangle_bytes);
         if (r->meshlet_triangles.upload(tri.data(), tri.size())) return 1;
     }
+    {
+        // positions and uv sets once more, in the order of meshlet_vertices (see SceneView::mpos_x)
+        const size_t n = (size_t)s.meshlet_vertex_count + 64;
+        std::vector<float> mx(n, 0.0f), my(n, 0.0f), mz(n, 0.0f);
+        std::vector<float4> muv(n, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        std::vector<uint32_t> owner(n, UINT32_MAX);
+        const char* indexed = std::getenv("RDR_RASTER_INDEXED"); // 1: leave the arrays out (the path through the indices, for tests)
+        bool ok = !(indexed && indexed[0] == '1');
+        for (uint32_t me = 0; me < s.mesh_count && ok; ++me)
+            for (uint32_t l = 0; l < s.meshes[me].lod_count && ok; ++l) {
+                const rdr_mesh_lod& L = s.meshes[me].lods[l];
+                for (uint32_t mi = L.meshlet_offset; mi < L.meshlet_offset + L.meshlet_count && ok; ++mi) {
+                    const rdr_meshlet& ml = s.meshlets[mi];
+                    for (uint32_t v = 0; v < ml.vertex_count; ++v) {
+                        const uint32_t slot = ml.vertex_offset + v, vi = s.meshes[me].vertex_offset + s.meshlet_vertices[slot];
+                        if (owner[slot] != UINT32_MAX && owner[slot] != vi) { ok = false; break; }
+                        owner[slot] = vi;
+                        const rdr_vertex& vx = s.vertices[vi];
+                        mx[slot] = vx.p[0]; my[slot] = vx.p[1]; mz[slot] = vx.p[2];
+                        muv[slot] = make_float4(vx.uv[0], vx.uv[1], vx.uv[2], vx.uv[3]);
+                    }
+                }
+            }
+        r->meshlet_order = ok;
+        if (ok) {
+            if (r->mpos_x.upload(mx.data(), n) || r->mpos_y.upload(my.data(), n) || r->mpos_z.upload(mz.data(), n) || r->muv.upload(muv.data(), n)) return 1;
+        }
+    }
     if (r->meshlets.upload(s.meshlets, s.meshlet_count)) return 1;
     if (r->meshes.upload(s.meshes, s.mesh_count)) return 1;
     if (r->draws.upload(s.mesh_draws, s.draw_count)) return 1;
@@ -851,6 +882,8 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
     sv.vertices = r->vertices.ptr;
     sv.pos_x = r->pos_x.ptr; sv.pos_y = r->pos_y.ptr; sv.pos_z = r->pos_z.ptr;
     sv.uv_sets = r->uv_sets.ptr;
+    sv.mpos_x = r->meshlet_order ? r->mpos_x.ptr : nullptr; sv.mpos_y = r->meshlet_order ? r->mpos_y.ptr : nullptr;
+    sv.mpos_z = r->meshlet_order ? r->mpos_z.ptr : nullptr; sv.muv = r->meshlet_order ? r->muv.ptr : nullptr;
     sv.meshlet_vertices = r->meshlet_vertices.ptr;
     sv.meshlet_triangles = r->meshlet_triangles.ptr;
     sv.meshlets = r->meshlets.ptr;

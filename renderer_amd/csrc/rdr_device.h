@@ -87,6 +87,24 @@ RDR_DEV void load_m4(const float* p, float* m) {
     for (int i = 0; i < 16; ++i) m[i] = p[i];
 }
 
+// A load through the constant address space, for data that no kernel of the running launch writes: at an address
+// that is the same in every lane the compiler uses the scalar unit (result in scalar registers, a counter of its
+// own, nothing on the vector memory path).
+template <typename T>
+RDR_DEV T load_uniform(const T* p) {
+    return *(const __attribute__((address_space(4))) T*)(p);
+}
+RDR_DEV void load_m4_uniform(const float* p, float* m) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = load_uniform(p + i);
+}
+// Four bytes at any byte address as one load (global memory takes unaligned dword accesses).
+RDR_DEV uint32_t load_u32_unaligned(const uint8_t* p) {
+    uint32_t w;
+    __builtin_memcpy(&w, p, 4);
+    return w;
+}
+
 RDR_DEV float model_max_scale(const float* m) {
     float sx = len3(mk3(m[0], m[1], m[2]));
     float sy = len3(mk3(m[4], m[5], m[6]));

@@ -631,6 +631,8 @@ RDR_DEV uint32_t scan_wave(const SceneView& sv, const FrameView& fv, const TriSe
 }
 
 // Per-wave LDS: the transformed vertices of one meshlet.
+// (One 16-byte element per vertex and phase instead of these planes — a corner in one LDS read — is slower: field
+// 0.144 -> 0.154 ms; 16-byte gathers are served 16 lanes at a time and collide more.)
 struct MeshletLds {
     float cx[64], cy[64], cz[64], cw[64]; // clip space
     float z[64];                          // z / w
@@ -650,13 +652,56 @@ struct MaskVertexLds<true> {
     FragTri rec[64]; // a lane's record for k_alpha_frag, staged here so that it does not sit in registers
 };
 
+// What one meshlet's pass reads from memory, fetched while the meshlet before it is being culled: a vertex position
+// per lane, the lane's two triangles (three index bytes each, in the low 24 bits of an unaligned dword), the draw's
+// model matrix (element k in lane k: a scalar load would be waited for by the very next LDS read, the two share a
+// counter), and for alpha-tested draws both uv sets of the lane's vertex.
+template <bool MASK>
+struct MeshletOperands {
+    float px, py, pz;
+    uint32_t tri_a, tri_b;
+    float model_lane;
+    float4 uv;
+};
+
+// One record of the visible list at a wave-uniform index, through the scalar unit.
+RDR_DEV VisibleMeshlet load_visible(const VisibleMeshlet* p) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(p);
+    VisibleMeshlet r;
+    r.draw_id = load_uniform(w + 0); r.meshlet_index = load_uniform(w + 1); r.instance = load_uniform(w + 2); r.model_index = load_uniform(w + 3);
+    r.vertex_offset = load_uniform(w + 4); r.triangle_offset = load_uniform(w + 5); r.counts = load_uniform(w + 6); r.mesh_vertex_offset = load_uniform(w + 7);
+    return r;
+}
+
+template <bool MASK>
+RDR_DEV void fetch_meshlet(const SceneView& sv, const VisibleMeshlet& r, uint32_t lane, MeshletOperands<MASK>& o) {
+    const uint32_t nv = r.counts & 0xFFu, nt = (r.counts >> 16) & 0xFFu;
+    o.px = o.py = o.pz = 0.0f;
+    o.uv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (lane < nv) {
+        if (sv.mpos_x) { // consecutive floats per plane, addressed by the record alone
+            const uint32_t s = r.vertex_offset + lane;
+            o.px = sv.mpos_x[s]; o.py = sv.mpos_y[s]; o.pz = sv.mpos_z[s];
+            if (MASK) o.uv = sv.muv[s];
+        } else {
+            const uint32_t vi = sv.meshlet_vertices[r.vertex_offset + lane] + r.mesh_vertex_offset;
+            o.px = sv.pos_x[vi]; o.py = sv.pos_y[vi]; o.pz = sv.pos_z[vi];
+            if (MASK) o.uv = sv.uv_sets[vi];
+        }
+    }
+    const uint8_t* tp = sv.meshlet_triangles + r.triangle_offset; // the buffer ends in 16 spare bytes
+    o.tri_a = lane < nt ? load_u32_unaligned(tp + lane * 3u) : 0u;
+    o.tri_b = lane + 64u < nt ? load_u32_unaligned(tp + (lane + 64u) * 3u) : 0u;
+    o.model_lane = lane < 16u ? sv.transforms[(size_t)r.model_index * 16 + lane] : 0.0f;
+}
+
 // MASK = false: meshlets of opaque draws (front of the visible list); MASK = true:
 // meshlets of alpha-tested draws (back of the list).  Two instantiations so that the
 // opaque one carries no uv / texture state in registers.
 // TOUCH: keep the sort-last tile flags (an instantiation of its own: the few registers the marking needs would
 // cost the plain opaque one its fifth wave per SIMD).
 template <bool MASK, bool TOUCH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : (TOUCH ? 5 : 1)))) void k_raster(SceneView sv, FrameView fv) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : 5))) void k_raster(SceneView sv, FrameView fv) {
     __shared__ MeshletLds lds;
     __shared__ MaskVertexLds<MASK> mlds;
     const uint32_t lane = threadIdx.x;
@@ -668,42 +713,49 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : (
 
     uint32_t st_tested = 0, st_raster = 0, st_big = 0, st_frags = 0, st_verts = 0;
     struct { uint32_t vertex_offset, triangle_offset, vertex_count, triangle_count; } m;
-    // Software pipeline over the wave's meshlets: the next record is requested a whole
-    // meshlet ahead and the next meshlet's vertex indices before this one's triangles, so
-    // that one dependent fetch (the positions) is what a meshlet still waits for.
+    // Software pipeline over the wave's meshlets.  Every operand of a meshlet (MeshletOperands) is requested while
+    // the meshlet before it runs its cull tests and is in registers before that meshlet's fragments are issued:
+    // a meshlet's pass then starts without a memory round trip, and none of its waits sits behind the atomics of
+    // the meshlet before (vector memory operations complete in order, so a wait placed after them would also wait
+    // for their acknowledgements).  The record itself comes a whole meshlet ahead through the scalar unit.
     VisibleMeshlet vm_next{};
-    uint32_t vi_next = 0;
+    MeshletOperands<MASK> next{};
+    auto record = [&](uint32_t i) { return load_visible(fv.visible + (MASK ? fv.visible_capacity - 1u - i : i)); };
+    // the loads of `next` have completed once their results have passed through here
+    auto settle = [&]() {
+        asm volatile("" : "+v"(next.px), "+v"(next.py), "+v"(next.pz), "+v"(next.tri_a), "+v"(next.tri_b), "+v"(next.model_lane));
+        if constexpr (MASK) asm volatile("" : "+v"(next.uv.x), "+v"(next.uv.y), "+v"(next.uv.z), "+v"(next.uv.w));
+    };
     if (blockIdx.x < vis_count) {
-        vm_next = fv.visible[MASK ? fv.visible_capacity - 1u - blockIdx.x : blockIdx.x];
-        if (lane < (vm_next.counts & 0xFFu)) vi_next = sv.meshlet_vertices[vm_next.vertex_offset + lane] + vm_next.mesh_vertex_offset;
+        vm_next = record(blockIdx.x);
+        fetch_meshlet<MASK>(sv, vm_next, lane, next);
     }
+    settle();
     for (uint32_t mi = blockIdx.x; mi < vis_count; mi += gridDim.x) {
         const VisibleMeshlet vm = vm_next;
-        const uint32_t vi = vi_next;
+        const MeshletOperands<MASK> op = next;
         const bool has_next = mi + gridDim.x < vis_count;
-        if (has_next) vm_next = fv.visible[MASK ? fv.visible_capacity - 1u - (mi + gridDim.x) : mi + gridDim.x];
         m.vertex_offset = vm.vertex_offset; m.triangle_offset = vm.triangle_offset;
         m.vertex_count = vm.counts & 0xFFu; m.triangle_count = (vm.counts >> 16) & 0xFFu;
         const uint32_t mesh_vertex_offset = vm.mesh_vertex_offset;
-        float model[16];
-        load_m4(sv.transforms + (size_t)vm.model_index * 16, model);
         AlphaTest at;
         at.enabled = false; at.has_tex = false;
         if (MASK) at = make_alpha_test(sv, sv.draws[vm.draw_id]);
         const bool cull_front = !MASK;
 
-        uint32_t first_tri = 0; // the lane's first triangle's vertex bytes, fetched ahead of the vertex phase
-        if (lane < m.triangle_count) {
-            const uint8_t* tp = sv.meshlet_triangles + m.triangle_offset + lane * 3;
-            first_tri = (uint32_t)tp[0] | ((uint32_t)tp[1] << 8) | ((uint32_t)tp[2] << 16);
-        }
-
         __syncthreads(); // previous meshlet's readers are done
+        // (after the barrier: the barrier waits for the scalar unit's loads together with the LDS operations)
+        if (has_next) vm_next = record(mi + gridDim.x);
+        float model[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) model[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, op.model_lane), k));
+        bool vert_behind = false, vert_clipped = false; // w <= 0; outside the near plane / guard band
         if (lane < m.vertex_count) {
             st_verts++;
-            const vec4 world = mul_m4(model, mk4(sv.pos_x[vi], sv.pos_y[vi], sv.pos_z[vi], 1.0f));
+            const vec4 world = mul_m4(model, mk4(op.px, op.py, op.pz, 1.0f));
             const vec4 clip = mul_m4(u.view_proj, world);
             lds.cx[lane] = clip.x; lds.cy[lane] = clip.y; lds.cz[lane] = clip.z; lds.cw[lane] = clip.w;
+            vert_behind = !(clip.w > 0.0f);
             const float rw = 1.0f / clip.w;
             lds.z[lane] = clip.z * rw;
             lds.sx[lane] = (clip.x * rw * 0.5f + 0.5f) * u.screen_width;
@@ -713,33 +765,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : (
             if (!nc) project_xy(clip.x, clip.y, rw, half_w, half_h, X, Y);
             lds.X[lane] = X; lds.Y[lane] = Y;
             lds.clip[lane] = nc ? 1u : 0u;
+            vert_clipped = nc;
             if constexpr (MASK) {
                 if (at.has_tex) { // perspective-correct uv for the alpha test
-                    const float4 uv = sv.uv_sets[vi];
                     mlds.inv_w[lane] = rw;
-                    mlds.u[lane] = at.uv_set ? uv.z : uv.x;
-                    mlds.v[lane] = at.uv_set ? uv.w : uv.y;
+                    mlds.u[lane] = at.uv_set ? op.uv.z : op.uv.x;
+                    mlds.v[lane] = at.uv_set ? op.uv.w : op.uv.y;
                 }
             }
         }
+        // Nearly every meshlet has all its vertices in front of the camera and inside the guard band: the triangle
+        // phases then skip the per-corner reads that would tell them so (wave-uniform branches).
+        const bool any_behind = __ballot(vert_behind) != 0ull, any_clipped = __ballot(vert_clipped) != 0ull;
         __syncthreads();
         if (TOUCH) touch_meshlet(fv, lane < m.vertex_count && lds.clip[lane] == 0u, lds.X, lds.Y, lane);
-        if (has_next && lane < (vm_next.counts & 0xFFu)) // in flight during the triangle phase
-            vi_next = sv.meshlet_vertices[vm_next.vertex_offset + lane] + vm_next.mesh_vertex_offset;
+        if (has_next) fetch_meshlet<MASK>(sv, vm_next, lane, next); // in flight during the cull tests
 
         // Triangle phase 1: the mesh shader's cull tests, two triangles per lane; the survivors (about
         // four in ten on a closed mesh) are packed into an LDS queue so that phase 2 runs on full lanes.
+        // (Testing the lane's two triangles together, so that their LDS reads overlap, costs registers the kernel
+        // does not have at five waves per SIMD: 12 bytes of scratch and 0.144 -> 0.154 ms on the field.)
         uint32_t n_queued = 0;
         for (uint32_t t0 = 0; t0 < m.triangle_count; t0 += 64) {
             const uint32_t ti = t0 + lane;
             bool keep = false;
             uint32_t packed = 0;
             if (ti < m.triangle_count) {
-                uint32_t tri_bytes = first_tri;
-                if (t0) {
-                    const uint8_t* tp = sv.meshlet_triangles + m.triangle_offset + ti * 3;
-                    tri_bytes = (uint32_t)tp[0] | ((uint32_t)tp[1] << 8) | ((uint32_t)tp[2] << 16);
-                }
+                const uint32_t tri_bytes = (t0 ? op.tri_b : op.tri_a) & 0xFFFFFFu;
                 const uint32_t ia = tri_bytes & 255u, ib = (tri_bytes >> 8) & 255u, ic = tri_bytes >> 16;
                 st_tested++;
                 const float ax = lds.sx[ia], ay = lds.sy[ia], bx = lds.sx[ib], by = lds.sy[ib];
@@ -750,7 +802,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : (
                 const float bmaxx = fmaxf(ax, fmaxf(bx, cx)), bmaxy = fmaxf(ay, fmaxf(by, cy));
                 const float sbprec = 1.0f / 256.0f;
                 culled = culled || (rintf(bminx - sbprec) == rintf(bmaxx) || rintf(bminy) == rintf(bmaxy + sbprec));
-                culled = culled && (lds.cw[ia] > 0.0f && lds.cw[ib] > 0.0f && lds.cw[ic] > 0.0f);
+                if (any_behind) culled = culled && (lds.cw[ia] > 0.0f && lds.cw[ib] > 0.0f && lds.cw[ic] > 0.0f);
                 keep = !culled;
                 packed = tri_bytes | (ti << 24);
             }
@@ -762,6 +814,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : (
             n_queued += (uint32_t)__popcll(km);
         }
         __syncthreads(); // the queue is complete
+        // the next meshlet's operands have arrived by now; taking them into registers here, before this meshlet's
+        // atomics, keeps the wait for them from covering those atomics as well
+        settle();
         // Triangle phase 2: set-up and scan of the queued triangles, one per lane
         for (uint32_t q0 = 0; q0 < n_queued; q0 += 64) {
             bool defer = false; // clipped, large or pixel-heavy triangles go to the tile path
@@ -770,10 +825,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : (
             uint32_t cmask = 0; // MASK: a lane-sized triangle's covered pixels (bit k: pixel k of its box, row-major)
                                 // (what k_alpha_frag needs of the triangle is staged in mlds.rec[lane])
             // snapped vertices of the triangle with meshlet-local vertices (a, b, c), from the wave's LDS
-            auto load_snap = [&](uint32_t a, uint32_t b, uint32_t c, SnapVert& s0, SnapVert& s1, SnapVert& s2) {
-                s0.X = lds.X[a]; s0.Y = lds.Y[a]; s0.z = lds.z[a];
-                s1.X = lds.X[b]; s1.Y = lds.Y[b]; s1.z = lds.z[b];
-                s2.X = lds.X[c]; s2.Y = lds.Y[c]; s2.z = lds.z[c];
+            auto load_snap = [&](uint32_t a, uint32_t b, uint32_t c, SnapVert& s0, SnapVert& s1, SnapVert& s2, bool positions) {
+                if (positions) {
+                    s0.X = lds.X[a]; s0.Y = lds.Y[a]; s0.z = lds.z[a];
+                    s1.X = lds.X[b]; s1.Y = lds.Y[b]; s1.z = lds.z[b];
+                    s2.X = lds.X[c]; s2.Y = lds.Y[c]; s2.z = lds.z[c];
+                }
                 s0.inv_w = s1.inv_w = s2.inv_w = 0.0f;
                 s0.u0 = s0.v0 = s0.u1 = s0.v1 = 0.0f;
                 s1.u0 = s1.v0 = s1.u1 = s1.v1 = 0.0f;
@@ -790,16 +847,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : (
             if (q0 + lane < n_queued) {
                 const uint32_t packed = lds.queue[q0 + lane];
                 ia = packed & 255u; ib = (packed >> 8) & 255u; ic = (packed >> 16) & 255u; ti = packed >> 24;
-                defer = (lds.clip[ia] | lds.clip[ib] | lds.clip[ic]) != 0u;
+                if (any_clipped) defer = (lds.clip[ia] | lds.clip[ib] | lds.clip[ic]) != 0u;
                 if (!defer) {
+                    // all nine reads at once: one LDS round trip in front of the set-up instead of two
                     const int32_t X0 = lds.X[ia], X1 = lds.X[ib], X2 = lds.X[ic];
                     const int32_t Y0 = lds.Y[ia], Y1 = lds.Y[ib], Y2 = lds.Y[ic];
+                    const float z0 = lds.z[ia], z1 = lds.z[ib], z2 = lds.z[ic];
                     const int32_t ex = max(X0, max(X1, X2)) - min(X0, min(X1, X2));
                     const int32_t ey = max(Y0, max(Y1, Y2)) - min(Y0, min(Y1, Y2));
                     defer = ex > kSmallExtent || ey > kSmallExtent;
                     if (!defer) {
                         SnapVert s0, s1, s2;
-                        load_snap(ia, ib, ic, s0, s1, s2);
+                        s0.X = X0; s0.Y = Y0; s0.z = z0; s1.X = X1; s1.Y = Y1; s1.z = z1; s2.X = X2; s2.Y = Y2; s2.z = z2;
+                        load_snap(ia, ib, ic, s0, s1, s2, false);
                         const TriSetup<int32_t> ts = setup_triangle<int32_t>(fv, s0, s1, s2, cull_front);
                         if (ts.valid) {
                             const int npx = (ts.px1 - ts.px0 + 1) * (ts.py1 - ts.py0 + 1);
@@ -893,7 +953,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : (
                         const uint32_t in_seg = base + ballot_rank(mm), slot = seg * seg_capacity + in_seg;
                         if (in_seg < seg_capacity) {
                             SnapVert s0, s1, s2;
-                            load_snap(ia, ib, ic, s0, s1, s2);
+                            load_snap(ia, ib, ic, s0, s1, s2, true);
                             SetupTri t;
                             SetupMask mk;
                             make_setup(fv, s0, s1, s2, cull_front, t, mk);

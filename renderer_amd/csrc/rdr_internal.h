@@ -298,6 +298,14 @@ struct SceneView {
     const float* pos_y;
     const float* pos_z;
     const float4* uv_sets;      // uv0.xy | uv1.zw per vertex, apart from the 64-byte vertex (the rasteriser's alpha test)
+    // The same four arrays in the order of meshlet_vertices (entry s = the vertex meshlet_vertices[s] names within
+    // its mesh): a meshlet's 64 positions are then 64 consecutive floats per plane that need nothing but the
+    // meshlet's record, not a gather behind an index load.  Null when two meshes with different vertex offsets
+    // share meshlets (an entry would mean two vertices); the rasteriser then goes through the indices.
+    const float* mpos_x;
+    const float* mpos_y;
+    const float* mpos_z;
+    const float4* muv;
     const uint32_t* meshlet_vertices;
     const uint8_t* meshlet_triangles;
     const rdr_meshlet* meshlets;
