@@ -501,7 +501,10 @@ template <typename I>
 RDR_DEV TriSetup<I> setup_triangle(const FrameView& fv, SnapVert v0, SnapVert v1, SnapVert v2, bool cull_front) {
     TriSetup<I> t;
     t.valid = false;
-    long long A = (long long)(v1.X - v0.X) * (v2.Y - v0.Y) - (long long)(v1.Y - v0.Y) * (v2.X - v0.X);
+    // twice the signed area; in the 32-bit instantiation the caller has bounded the extents (kSmallExtent), so
+    // the products fit 32 bits and (float)A rounds the same integer once either way
+    static_assert(sizeof(I) == 8 || (long long)kSmallExtent * kSmallExtent * 2 < (1ll << 31), "32-bit set-up: area overflows");
+    I A = (I)(v1.X - v0.X) * (I)(v2.Y - v0.Y) - (I)(v1.Y - v0.Y) * (I)(v2.X - v0.X);
     if (A == 0) return t;
     if (A > 0) {
         // clockwise on the y-down screen: front-facing under frontFace = CLOCKWISE
