@@ -110,6 +110,46 @@ def test_alpha_masked_field(oracle):
     check_color(o, g)
 
 
+def test_vertex_fetch_through_the_indices_is_result_neutral(oracle, monkeypatch):
+    """The rasteriser reads a meshlet's positions and uv sets from copies laid out in meshlet_vertices order; without
+    them (RDR_RASTER_INDEXED=1) it goes through the indices: the same buffer, opaque and alpha-masked."""
+    monkeypatch.setenv("RDR_RASTER_INDEXED", "1")
+    sc = synth.make_field(60, 3, alpha_fraction=0.5)
+    sc.camera = Camera((0.0, 4.0, -14.0), (0.0, 0.25, -1.0))
+    o, ovis, g = both(oracle, sc, 320, 180)
+    check_vis(o, ovis, g)
+    check_color(o, g)
+    o, ovis, g = both(oracle, synth.make_atrium(), 256, 144, shade=False)
+    check_vis(o, ovis, g)
+
+
+def test_meshes_that_share_meshlets(oracle):
+    """Two meshes over the same meshlets and indices but different vertices (a second vertex_offset): an entry of
+    meshlet_vertices then names two vertices, the copies in meshlet order cannot exist, and the library has to notice
+    that by itself and fetch through the indices."""
+    sc = synth.make_field(1, 3, lods=2)
+    first = sc.meshes[0].copy()
+    twin = first.copy()
+    twin["vertex_offset"] = len(sc.vertices)
+    twin["index_offset"] = len(sc.indices)
+    verts = sc.vertices[int(first["vertex_offset"]):int(first["vertex_offset"]) + int(first["vertex_count"])].copy()
+    verts["p"][:, :3] *= np.float32(1.4)  # a different shape, so that fetching the first mesh's vertices would show
+    verts["p"][:, 1] *= np.float32(0.6)
+    twin["radius"] = first["radius"] * np.float32(1.4)
+    sc.vertices = np.concatenate([sc.vertices, verts])
+    lo = int(first["index_offset"])
+    sc.indices = np.concatenate([sc.indices, sc.indices[lo:]])
+    sc.meshes = np.concatenate([sc.meshes, twin.reshape(1)])
+    sc.add_draw(1, mat4_trs((2.5, 0.0, 0.0)))
+    sc.add_draw(0, mat4_trs((-2.5, 0.5, 1.0)))
+    sc.add_draw(1, mat4_trs((0.0, 2.0, 3.0), scale=(0.7, 0.7, 0.7)))
+    sc.camera = Camera((0.0, 1.0, -9.0), (0.0, 0.0, -1.0))
+    o, ovis, g = both(oracle, sc, 320, 180)
+    assert covered(ovis).sum() > 2000
+    check_vis(o, ovis, g)
+    check_color(o, g)
+
+
 @pytest.mark.parametrize("lane_max,mid_max", [(1, 1), (1, 4096), (4096, 4096), (16, 64)])
 def test_raster_routing_is_result_neutral(oracle, monkeypatch, lane_max, mid_max):
     """Which of the three rasterisers (per-lane scan, wave per triangle, tile bins) takes a
