@@ -635,7 +635,10 @@ RDR_DEV uint32_t scan_wave(const SceneView& sv, const FrameView& fv, const TriSe
 
 // Per-wave LDS: the transformed vertices of one meshlet.
 // (One 16-byte element per vertex and phase instead of these planes — a corner in one LDS read — is slower: field
-// 0.144 -> 0.154 ms; 16-byte gathers are served 16 lanes at a time and collide more.)
+// 0.144 -> 0.154 ms; 16-byte gathers are served 16 lanes at a time and collide more.  So is keeping a vertex in the
+// registers of its lane and fetching it with ds_bpermute, which needs no LDS writes and no waits between the phases:
+// 0.137 -> 0.146 ms.  Wave-level work counters in scalar registers (four vector registers fewer) and compiler-only
+// barriers between the phases (one wave per workgroup needs no more): 0.136 -> 0.138 ms, Field-XL 1.95 -> 2.00 ms.)
 struct MeshletLds {
     float cx[64], cy[64], cz[64], cw[64]; // clip space
     float z[64];                          // z / w
