@@ -1,4 +1,7 @@
-# scratch experiment runner (GPU box): parity first, then kernel times of the library variants
+# Kernel experiments on the GPU box: the parity tests that cover the rasterisers first, then the kernel times of
+# alternative builds of the library side by side (LIBS: paths under renderer_amd/, e.g. "variants/libbase.so librdr_hip.so";
+# a variant is the same objects linked with one file rebuilt differently, see profiles/sweep_lib.sh).
+#   LIBS="variants/libbase.so librdr_hip.so" bash profiles/variant_check.sh
 set -e
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
