@@ -400,6 +400,28 @@ RDR_DEV float model_stretch_bound(const float* m) {
 // an instance that is not collected cannot be hit.  Up to kSunCandidates are kept (more, or a stack overflow: the
 // shadow rays walk the top level as before).  Depends on the sun direction and the transforms only: launched
 // when either has changed (rdr_shade), not per frame.
+// The world-space ball around the mesh the ray structure holds for draw `di` (centre, radius; w = 0: unknown).
+RDR_DEV float4 instance_world_ball(const SceneView& sv, uint32_t di, const float* model) {
+    const float4 ball = sv.instance_ball[di];
+    const vec4 cw = mul_m4(model, mk4(ball.x, ball.y, ball.z, 1.0f));
+    const float r0 = sv.instances[di].outer_radius * model_stretch_bound(model) * 1.001f + 1e-5f * (1.0f + fmaxf(fabsf(cw.x), fmaxf(fabsf(cw.y), fabsf(cw.z))));
+    return (r0 > 0.0f && r0 < 1e30f) ? make_float4(cw.x, cw.y, cw.z, r0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// Can a ray with direction L (unit length) that starts within R of c meet the ball `wb`?  No when the ball's centre is
+// farther from the line through c than R plus its radius, or when the whole ball lies behind every such origin; the
+// margin covers the rounding of the difference of two far-apart positions.  An unknown ball (w = 0) can.
+RDR_DEV bool fat_ray_reaches_ball(vec3 c, vec3 L, float R, float4 wb) {
+    if (!(wb.w > 0.0f)) return true;
+    const vec3 v = mk3(wb.x - c.x, wb.y - c.y, wb.z - c.z);
+    const float t = dot3(v, L);
+    const vec3 w = v - L * t;
+    const float thr = (R + wb.w) * 1.0001f + 4e-5f * (1.0f + (fabsf(v.x) + fabsf(v.y)) + fabsf(v.z));
+    if (dot3(w, w) > thr * thr) return false;
+    if (t + thr < 0.0f) return false;
+    return true;
+}
+
 __global__ __launch_bounds__(256) void k_sun_candidates(SceneView sv, FrameView fv) {
     __shared__ uint32_t stack_mem[(kLdsStack + 1) * 256];
     const uint32_t di = blockIdx.x * 256u + threadIdx.x;
@@ -413,11 +435,8 @@ __global__ __launch_bounds__(256) void k_sun_candidates(SceneView sv, FrameView 
         load_m4(sv.transforms + (size_t)sv.draws[di].model_index * 16, model);
         const vec4 cw = mul_m4(model, mk4(ball.x, ball.y, ball.z, 1.0f));
         const vec3 c = mk3(cw.x, cw.y, cw.z);
-        {
-            // the ball around the mesh the ray structure holds, in world space (for the pre-test in front of an instance's walk)
-            const float r0 = sv.instances[di].outer_radius * model_stretch_bound(model) * 1.001f + 1e-5f * (1.0f + fmaxf(fabsf(c.x), fmaxf(fabsf(c.y), fabsf(c.z))));
-            if (r0 > 0.0f && r0 < 1e30f) wball = make_float4(c.x, c.y, c.z, r0);
-        }
+        // the ball around the mesh the ray structure holds, in world space (for the pre-test in front of an instance's walk)
+        wball = instance_world_ball(sv, di, model);
       if (fv.sun_candidates) {
         // world-space radius with room for the rounding of an origin (interpolated world position) and of this sum
         const float R = reach * model_stretch_bound(model) * 1.001f + 1e-4f * (1.0f + fmaxf(fabsf(c.x), fmaxf(fabsf(c.y), fabsf(c.z))));
@@ -451,6 +470,12 @@ __global__ __launch_bounds__(256) void k_sun_candidates(SceneView sv, FrameView 
                 for (uint32_t i = 0; i < items; ++i) {
                     const uint32_t other = sv.tlas_items[first + i];
                     if (other == di) continue;
+                    // A leaf was reached because its box is; the instances in it are then held to their own balls, which
+                    // on a field of like-sized neighbours leaves most lists empty (every pixel of such an instance then
+                    // skips the world level of its shadow ray altogether).
+                    float other_model[16];
+                    load_m4(sv.transforms + (size_t)sv.draws[other].model_index * 16, other_model);
+                    if (!fat_ray_reaches_ball(c, L, R, instance_world_ball(sv, other, other_model))) continue;
                     if (n < kSunCandidates) out[n] = other;
                     ++n;
                 }

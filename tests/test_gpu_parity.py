@@ -328,6 +328,54 @@ def test_sun_candidates_under_sheared_instances(oracle, monkeypatch):
     plain.close()
 
 
+def test_sun_candidates_at_the_edge_of_an_occluders_reach(monkeypatch):
+    """An instance stays on its neighbour's list of possible sun occluders as long as its ball reaches the bundle of sun
+    rays that start on the neighbour.  A sphere slides past the sun line of another, from well inside that bundle to
+    well outside it in small steps, under a sheared transform as well: the image with the lists equals the image
+    without them at every step, and the shadow is there at one end of the sweep and gone at the other."""
+    sc = synth.make_field(1, 3, lods=1, with_env=True, prepared=True)
+    sun = np.array((0.35, 0.9, 0.1))
+    sun /= np.linalg.norm(sun)
+    side = np.cross(sun, (0.0, 0.0, 1.0))
+    side /= np.linalg.norm(side)
+    base = np.array(sc.global_transforms, dtype=np.float32).reshape(-1, 16)[0].reshape(4, 4).T.copy()  # the receiver
+    centre = base[:3, 3].astype(np.float64)
+    scale = float(np.linalg.norm(base[:3, 0]))
+    sc.add_draw(0, base.T.reshape(16), 0)  # the occluder's draw (moved below)
+    w, h = 320, 180
+    conf = RendererConfig(lod_enabled=False, cull_enabled=False)
+    cam = Camera((float(centre[0]), float(centre[1]) + 2.0, float(centre[2]) - 5.0), (0.0, 0.3, -1.0))
+    g = Renderer(w, h, conf)
+    g.set_scene(sc)
+    monkeypatch.setenv("RDR_SUN_CANDIDATES", "0")
+    plain = Renderer(w, h, conf)
+    monkeypatch.delenv("RDR_SUN_CANDIDATES")
+    plain.set_scene(sc)
+    dark = []
+    for shear in (0.0, 0.8):
+        for off in np.linspace(0.0, 2.6 * scale, 14):
+            m = base.copy()
+            m[:3, :3] *= np.float32(0.6)
+            m[0, 1] += np.float32(shear * 0.6 * scale)
+            m[:3, 3] = (centre + sun * 3.0 * scale + side * off).astype(np.float32)
+            t = np.array(sc.global_transforms, dtype=np.float32).reshape(-1, 16).copy()
+            t[1] = m.T.reshape(16)
+            g.update_transforms(t)
+            plain.update_transforms(t)
+            g.render(cam, tuple(sun))
+            plain.render(cam, tuple(sun))
+            assert np.array_equal(g.read_visbuffer_u64(), plain.read_visbuffer_u64())
+            a, b = g.read_color(), plain.read_color()
+            assert np.array_equal(a, b), (shear, off)
+            receiver = g.read_visbuffer().reshape(h, w, 2)[..., 1] == 0
+            dark.append((a[..., :3].astype(int).sum(axis=2), receiver))
+    for first, last in ((0, 13), (14, 27)):  # the shadow on the receiver is there at one end of a sweep and gone at the other
+        both = dark[first][1] & dark[last][1]
+        assert ((dark[last][0] - dark[first][0])[both] > 60).sum() > 50
+    g.close()
+    plain.close()
+
+
 def _cube_mesh():
     """A closed unit cube (half-extent 1) as six outward-facing quads in one mesh."""
     faces = [[(1, -1, -1), (1, 1, -1), (1, 1, 1), (1, -1, 1)], [(-1, -1, 1), (-1, 1, 1), (-1, 1, -1), (-1, -1, -1)],
