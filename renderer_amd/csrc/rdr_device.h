@@ -94,6 +94,12 @@ template <typename T>
 RDR_DEV T load_uniform(const T* p) {
     return *(const __attribute__((address_space(4))) T*)(p);
 }
+// The same for a record that is read field by field: a reference through which every field the lanes agree on the
+// address of is a scalar load (and an ordinary vector load where they do not).
+template <typename T>
+RDR_DEV const __attribute__((address_space(4))) T& uniform_ref(const T* p) {
+    return *(const __attribute__((address_space(4))) T*)(p);
+}
 RDR_DEV void load_m4_uniform(const float* p, float* m) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) m[i] = load_uniform(p + i);
@@ -203,7 +209,8 @@ RDR_DEV TexelPair load_texel_pair(const uint8_t* p) {
     return TexelPair{v.x, v.y};
 }
 
-RDR_DEV vec4 image_bilinear(const GpuImage& im, const uint8_t* texels, const float* lut, uint32_t level,
+template <typename Image> // GpuImage, or GpuImage in the constant address space (uniform_ref)
+RDR_DEV vec4 image_bilinear(const Image& im, const uint8_t* texels, const float* lut, uint32_t level,
                             float u, float v, bool lut_linear = false) {
     const int w = (int)mip_dim(im.width, level), h = (int)mip_dim(im.height, level);
     const uint8_t* base = texels + im.offset + im.level_offset[level];
@@ -234,7 +241,8 @@ RDR_DEV vec4 image_bilinear(const GpuImage& im, const uint8_t* texels, const flo
     return lerp4(lerp4(t00, t10, ax), lerp4(t01, t11, ax), ay);
 }
 
-RDR_DEV vec4 image_sample_lod(const GpuImage& im, const uint8_t* texels, const float* lut, float u, float v,
+template <typename Image> // GpuImage, or GpuImage in the constant address space (uniform_ref)
+RDR_DEV vec4 image_sample_lod(const Image& im, const uint8_t* texels, const float* lut, float u, float v,
                               float lod, bool lut_linear = false) {
     float maxl = (float)(im.mip_count - 1);
     if (maxl > 16.0f) maxl = 16.0f;
@@ -250,7 +258,8 @@ RDR_DEV vec4 image_sample_lod(const GpuImage& im, const uint8_t* texels, const f
     return lerp4(a, b, t);
 }
 
-RDR_DEV vec4 image_sample_grad(const GpuImage& im, const uint8_t* texels, const float* lut, float u, float v,
+template <typename Image> // GpuImage, or GpuImage in the constant address space (uniform_ref)
+RDR_DEV vec4 image_sample_grad(const Image& im, const uint8_t* texels, const float* lut, float u, float v,
                                float dudx, float dvdx, float dudy, float dvdy, bool lut_linear = false) {
     const float w = (float)im.width, h = (float)im.height;
     const float ax = dudx * w, ay = dvdx * h, bx = dudy * w, by = dvdy * h;

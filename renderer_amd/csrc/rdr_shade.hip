@@ -30,8 +30,10 @@ RDR_DEV InterpUv uv_transform(InterpUv in, float sx, float sy, float ox, float o
 
 RDR_DEV vec4 sample_or_default(const SceneView& sv, const float* lut, uint32_t tex, InterpUv uv, vec4 def) {
     if (tex == RDR_NO_TEXTURE) return def;
-    if (tex >= sv.image_count || sv.images[tex].mip_count == 0u) return mk4(0.0f, 0.0f, 0.0f, 0.0f);
-    return image_sample_grad(sv.images[tex], sv.texels, lut, uv.u, uv.v, uv.dudx, uv.dvdx, uv.dudy, uv.dvdy, true);
+    if (tex >= sv.image_count) return mk4(0.0f, 0.0f, 0.0f, 0.0f);
+    const auto& im = uniform_ref(&sv.images[tex]);
+    if (im.mip_count == 0u) return mk4(0.0f, 0.0f, 0.0f, 0.0f);
+    return image_sample_grad(im, sv.texels, lut, uv.u, uv.v, uv.dudx, uv.dvdx, uv.dudy, uv.dvdy, true);
 }
 
 // ---- BRDF terms -------------------------------------------------------------------
@@ -156,14 +158,17 @@ RDR_DEV uint32_t srgb_encode(float c) {
 }
 
 // `srgb`: the sRGB decode table (SceneView::srgb_lut or a copy of it)
-RDR_DEV vec3 shade_pixel(const SceneView& sv, const float* srgb, const FrameView& fv, const ListedPixel& px, bool shadow_hit) {
+// `material`: the pixel's material, or material_count for an index past the end; the same in every lane that is in here
+// together (k_shade takes a wave's materials one at a time), so that everything read of the material, of its textures'
+// descriptors, and every branch on its type goes through the scalar unit.
+RDR_DEV vec3 shade_pixel(const SceneView& sv, const float* srgb, const FrameView& fv, const ListedPixel& px, uint32_t material, bool shadow_hit) {
     const rdr_ubo& u = fv.ubo;
     const float uvx = px.uvx, uvy = px.uvy;
     float model[16];
     load_m4(sv.transforms + (size_t)px.model_index * 16, model);
     // fields are read where they are used (the copy of all 272 bytes held some forty registers through the texture taps);
     // an index past the end lands on the zero material the upload appends
-    const rdr_material& mat = sv.materials[px.material_index < sv.material_count ? px.material_index : sv.material_count];
+    const auto& mat = uniform_ref(&sv.materials[material]);
     const rdr_vertex* v1 = &sv.vertices[px.i1];
     const rdr_vertex* v2 = &sv.vertices[px.i2];
     const rdr_vertex* v3 = &sv.vertices[px.i3];
@@ -306,7 +311,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __syncthreads();
     if (entry >= count) return;
     const ListedPixel p = listed_pixel(sv, fv, entry);
-    const vec3 c = shade_pixel(sv, lut, fv, p, fv.shadow[entry] != 0);
+    const uint32_t material = p.material_index < sv.material_count ? p.material_index : sv.material_count;
+    const bool shadow_hit = fv.shadow[entry] != 0;
+    vec3 c = mk3(0.0f, 0.0f, 0.0f);
+    // One material of the wave at a time (usually there is one).  The first pending lane's material is read with
+    // inline assembly: the intrinsic's operand does not change in the loop, so the compiler would move the call in
+    // front of it (every round would then see the first lane's material); and read once more inside the branch,
+    // where all lanes agree, because the compiler puts the lane's own copy, which it knows to be equal, in the place
+    // of the value compared against, and with it every address would be a vector again.
+    bool done = false;
+    while (!done) {
+        uint32_t first;
+        asm volatile("v_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(first) : "v"(material));
+        if (material == first) {
+            uint32_t m;
+            asm volatile("v_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(m) : "v"(material));
+            c = shade_pixel(sv, lut, fv, p, m, shadow_hit);
+            done = true;
+        }
+    }
     reinterpret_cast<uint32_t*>(fv.color)[p.pi] =
         srgb_encode(c.x) | (srgb_encode(c.y) << 8) | (srgb_encode(c.z) << 16) | (255u << 24);
 }
