@@ -100,6 +100,26 @@ template <typename T>
 RDR_DEV const __attribute__((address_space(4))) T& uniform_ref(const T* p) {
     return *(const __attribute__((address_space(4))) T*)(p);
 }
+// body(k) once for every distinct value k of `key` among the wave's active lanes, with the lanes that hold k active
+// and k in a scalar register: what body reads at addresses derived from k goes through the scalar unit (uniform_ref,
+// load_uniform).  The loop itself is uniform (a scalar mask of the lanes still to serve; the branch is inside it):
+// written as a loop that every lane leaves after its own turn, the compiler rotates it into "wait for your turn,
+// then do the work once behind the loop", where all lanes are back and the scalar value is the first lane's.  The
+// comparison goes through an opaque copy of k, because inside the branch the compiler would otherwise put the lane's
+// own key, which it knows to be equal, in k's place, and every address would be a vector again.
+template <typename F>
+RDR_DEV void for_each_uniform(uint32_t key, F&& body) {
+    unsigned long long pending = __ballot(true);
+    while (pending) {
+        const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, __ffsll((long long)pending) - 1);
+        uint32_t k_compare = k;
+        asm volatile("" : "+s"(k_compare));
+        const bool mine = key == k_compare;
+        if (mine) body(k);
+        pending &= ~__ballot(mine);
+    }
+}
+
 RDR_DEV void load_m4_uniform(const float* p, float* m) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) m[i] = load_uniform(p + i);

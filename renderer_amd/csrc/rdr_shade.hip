@@ -314,22 +314,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint32_t material = p.material_index < sv.material_count ? p.material_index : sv.material_count;
     const bool shadow_hit = fv.shadow[entry] != 0;
     vec3 c = mk3(0.0f, 0.0f, 0.0f);
-    // One material of the wave at a time (usually there is one).  The first pending lane's material is read with
-    // inline assembly: the intrinsic's operand does not change in the loop, so the compiler would move the call in
-    // front of it (every round would then see the first lane's material); and read once more inside the branch,
-    // where all lanes agree, because the compiler puts the lane's own copy, which it knows to be equal, in the place
-    // of the value compared against, and with it every address would be a vector again.
-    bool done = false;
-    while (!done) {
-        uint32_t first;
-        asm volatile("v_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(first) : "v"(material));
-        if (material == first) {
-            uint32_t m;
-            asm volatile("v_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(m) : "v"(material));
-            c = shade_pixel(sv, lut, fv, p, m, shadow_hit);
-            done = true;
-        }
-    }
+    // one material of the wave at a time (usually there is one)
+    for_each_uniform(material, [&](uint32_t m) { c = shade_pixel(sv, lut, fv, p, m, shadow_hit); });
     reinterpret_cast<uint32_t*>(fv.color)[p.pi] =
         srgb_encode(c.x) | (srgb_encode(c.y) << 8) | (srgb_encode(c.z) << 16) | (255u << 24);
 }

@@ -110,6 +110,31 @@ def test_alpha_masked_field(oracle):
     check_color(o, g)
 
 
+def test_many_materials_in_one_wave(oracle):
+    """The shading pass takes the materials of a wave of 64 pixels one at a time.  Small instances with thirteen
+    different materials (all material models among them) in turn put four and more materials into most waves, and an
+    index past the end of the material table shades with the all-zero material."""
+    sc = synth.make_field(1, 3, lods=1, with_env=True)
+    rng = np.random.default_rng(11)
+    kinds = [abi.MAT_METAL_ROUGHNESS, abi.MAT_SPEC_GLOSS, abi.MAT_METAL_ROUGHNESS | abi.MAT_CLEARCOAT,
+             abi.MAT_METAL_ROUGHNESS | abi.MAT_SHEEN, abi.MAT_METAL_ROUGHNESS | abi.MAT_SPEC]
+    for k in range(12):
+        sc.add_material(material_type=kinds[k % len(kinds)], base_color_factor=tuple(rng.uniform(0.1, 1.0, 3)) + (1.0,),
+                        metallic_roughness_normal_occlusion=(float(rng.uniform(0, 1)), float(rng.uniform(0.1, 1)), 1, 1),
+                        clearcoat_factor=(0.7, 0.2, 0, 0), sheen_color_roughness_factor=(0.8, 0.5, 0.7, 0.5),
+                        specular_factor=(1.0, 0.6, 0.5, 0.7), specular_glossiness_factor=(0.3, 0.4, 0.35, 0.6))
+    side = 40
+    for i in range(side * side):
+        x, z = (i % side - side / 2) * 0.22, (i // side) * 0.22
+        material = 0xFFFF if i % 17 == 0 else i % 13
+        sc.add_draw(0, mat4_trs((x, 0.0, z), scale=(0.1, 0.1, 0.1)), material)
+    sc.camera = Camera((0.0, 3.0, -2.5), (0.0, 0.45, -1.0))
+    o, ovis, g = both(oracle, sc, 480, 270)
+    assert covered(ovis).sum() > 20000
+    check_vis(o, ovis, g)
+    check_color(o, g)
+
+
 def test_vertex_fetch_through_the_indices_is_result_neutral(oracle, monkeypatch):
     """The rasteriser reads a meshlet's positions and uv sets from copies laid out in meshlet_vertices order; without
     them (RDR_RASTER_INDEXED=1) it goes through the indices: the same buffer, opaque and alpha-masked."""
