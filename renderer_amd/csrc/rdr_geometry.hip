@@ -252,17 +252,18 @@ __global__ __launch_bounds__(1024) void k_meshlet_cull(SceneView sv, FrameView f
         uint32_t model_index = 0, mesh_vertex_offset = 0, m_vertex_offset = 0, m_triangle_offset = 0, m_counts = 0, replicated = 0;
         bool emit = false;
         if (ci < cmd_count) {
-            const CullCommand* cp = &fv.commands[__builtin_amdgcn_readfirstlane(ci)];
+            // the command and everything it leads to is the same for the whole wave: read through the scalar unit
+            const auto* cp = &uniform_ref(&fv.commands[__builtin_amdgcn_readfirstlane(ci)]);
             draw_id = cp->draw_id; first = cp->meshlet_first; count = cp->count;
             instance_first = cp->instance_first;
             replicated = cp->replicated;
             const float max_scale = cp->max_scale;
-            const rdr_mesh_draw d = sv.draws[draw_id];
+            const auto& d = uniform_ref(&sv.draws[draw_id]);
             model_index = d.model_index;
-            mesh_vertex_offset = sv.meshes[d.mesh_index].vertex_offset;
+            mesh_vertex_offset = uniform_ref(&sv.meshes[d.mesh_index]).vertex_offset;
             masked = d.alpha_mode == 1u ? 1u : 0u;
             float model[16];
-            load_m4(sv.transforms + (size_t)model_index * 16, model);
+            load_m4_uniform(sv.transforms + (size_t)model_index * 16, model);
             accept = lane < count;
             if (accept) {
                 const rdr_meshlet m = sv.meshlets[first + lane];
@@ -1035,7 +1036,13 @@ RDR_DEV void mid_raster_role(const SceneView& sv, const FrameView& fv, uint32_t 
     for (uint32_t i = wave; i < count; i += n_waves) {
         const uint32_t seg = (uint32_t)__popcll(__ballot(lane < kMidSegments && seg_end <= i)); // segments that end at or before i
         const uint32_t r = seg * seg_capacity + (i - (__shfl(seg_end, (int)seg, 64) - __shfl(seg_n, (int)seg, 64)));
-        const SetupTri t = fv.mid[r]; // the same address in every lane: one broadcast load
+        SetupTri t; // the same record in every lane: through the scalar unit
+        {
+            const uint32_t* words = reinterpret_cast<const uint32_t*>(&fv.mid[__builtin_amdgcn_readfirstlane(r)]);
+            uint32_t* out = reinterpret_cast<uint32_t*>(&t);
+#pragma unroll
+            for (uint32_t k = 0; k < sizeof(SetupTri) / 4u; ++k) out[k] = load_uniform(words + k);
+        }
         TriSetup<int32_t> ts;
         ts.v0 = SnapVert{}; ts.v1 = SnapVert{}; ts.v2 = SnapVert{};
         ts.v0.X = t.X0; ts.v0.Y = t.Y0; ts.v1.X = t.X1; ts.v1.Y = t.Y1; ts.v2.X = t.X2; ts.v2.Y = t.Y2;
