@@ -366,7 +366,10 @@ struct AlphaTest {
     float sx, sy, ox, oy, factor_a, cutoff;
 };
 
-RDR_DEV AlphaTest make_alpha_test(const SceneView& sv, const rdr_mesh_draw& d) {
+// `d`: the draw, as a plain reference or through uniform_ref where the whole wave works on one draw; the material and
+// the image descriptor behind it are then scalar loads as well.
+template <typename Draw>
+RDR_DEV AlphaTest make_alpha_test(const SceneView& sv, const Draw& d) {
     AlphaTest at;
     at.enabled = d.alpha_mode == 1u;
     at.has_tex = false;
@@ -374,11 +377,11 @@ RDR_DEV AlphaTest make_alpha_test(const SceneView& sv, const rdr_mesh_draw& d) {
     at.sx = at.sy = at.ox = at.oy = 0.0f;
     at.factor_a = 0.0f; at.cutoff = 0.0f; // material_index past the end reads zeros
     if (at.enabled && d.material_index < sv.material_count) {
-        const rdr_material* mat = &sv.materials[d.material_index];
+        const auto* mat = &uniform_ref(&sv.materials[d.material_index]);
         at.factor_a = mat->base_color_factor[3];
         at.cutoff = mat->emissive_factor_alpha_cutoff[3];
         const uint32_t tex = mat->albedo_texture;
-        if (tex != RDR_NO_TEXTURE && tex < sv.image_count && sv.images[tex].mip_count == 0u) {
+        if (tex != RDR_NO_TEXTURE && tex < sv.image_count && uniform_ref(&sv.images[tex]).mip_count == 0u) {
             at.factor_a = 0.0f; // an image without data samples as zero (as in the shading pass): alpha = 0 * factor
         } else if (tex != RDR_NO_TEXTURE && tex < sv.image_count) {
             at.has_tex = true;
@@ -559,7 +562,7 @@ RDR_DEV uint32_t shade_sample(const SceneView& sv, const FrameView& fv, const Tr
             u = u * at.sx + at.ox; v = v * at.sy + at.oy;
             ux = ux * at.sx + at.ox; vx = vx * at.sy + at.oy;
             uy = uy * at.sx + at.ox; vy = vy * at.sy + at.oy;
-            alpha = image_sample_grad(sv.images[at.image], sv.texels, sv.srgb_lut, u, v, ux - u, vx - v, uy - u, vy - v).w;
+            alpha = image_sample_grad(uniform_ref(&sv.images[at.image]), sv.texels, sv.srgb_lut, u, v, ux - u, vx - v, uy - u, vy - v).w;
         }
         alpha = alpha * at.factor_a;
         if (alpha < at.cutoff) return 0;
@@ -747,7 +750,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : 5
         const uint32_t mesh_vertex_offset = vm.mesh_vertex_offset;
         AlphaTest at;
         at.enabled = false; at.has_tex = false;
-        if (MASK) at = make_alpha_test(sv, sv.draws[vm.draw_id]);
+        if (MASK) at = make_alpha_test(sv, uniform_ref(&sv.draws[vm.draw_id]));
         const bool cull_front = !MASK;
 
         __syncthreads(); // previous meshlet's readers are done
@@ -1057,7 +1060,7 @@ RDR_DEV void mid_raster_role(const SceneView& sv, const FrameView& fv, uint32_t 
         ts.px0 = t.px0; ts.py0 = t.py0; ts.px1 = t.px1; ts.py1 = t.py1;
         ts.valid = true;
         if (t.masked & 2u) { // alpha-tested draw (the record says so: no dependent load for the opaque majority)
-            const AlphaTest at = make_alpha_test(sv, sv.draws[t.draw_id]);
+            const AlphaTest at = make_alpha_test(sv, uniform_ref(&sv.draws[t.draw_id]));
             if (t.masked & 1u) {
                 const SetupMask* mk = &fv.mid_mask[r];
                 SnapVert* vs[3] = {&ts.v0, &ts.v1, &ts.v2};
@@ -1693,7 +1696,7 @@ RDR_DEV void tile_raster_role(const SceneView& sv, const FrameView& fv, uint32_t
                     }
                     continue;
                 }
-                const AlphaTest at = make_alpha_test(sv, sv.draws[t.draw_id]);
+                const AlphaTest at = make_alpha_test(sv, uniform_ref(&sv.draws[__builtin_amdgcn_readfirstlane(t.draw_id)])); // one record for all threads
                 const SetupMask* mk = (t.masked & 1u) ? &fv.setup_mask[batch_index[k]] : nullptr;
                 // alpha-tested: coverage of the block first, then the texture is consulted only where it matters
                 uint32_t cov = 0;
@@ -1740,7 +1743,7 @@ RDR_DEV void tile_raster_role(const SceneView& sv, const FrameView& fv, uint32_t
                         if (at.enabled) {
                             float alpha = 1.0f;
                             if (textured)
-                                alpha = image_sample_grad(sv.images[at.image], sv.texels, sv.srgb_lut, ru[i], rv[i], ru[i + 1] - ru[i],
+                                alpha = image_sample_grad(uniform_ref(&sv.images[at.image]), sv.texels, sv.srgb_lut, ru[i], rv[i], ru[i + 1] - ru[i],
                                                           rv[i + 1] - rv[i], nu[i] - ru[i], nv[i] - rv[i]).w;
                             alpha = alpha * at.factor_a;
                             if (alpha < at.cutoff) continue;
