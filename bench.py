@@ -358,11 +358,13 @@ def main():
             "roofline": {"kernel": "k_" + dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          # the contract's bound is HBM or MFMA; of the two this path can only meet HBM, but none of the three
-                         # large kernels is limited by bandwidth (valu_issue: share of vector issue slots used, lanes active)
-                         "limited_by": {"raster": "vector issue and LDS round trips per meshlet (a third of the issue slots, two thirds of the lanes), "
+                         # large kernels is limited by bandwidth (valu_issue: share of its cycles the SIMDs spent issuing vector
+                         # instructions at 4 cycles each, and the lanes active in them)
+                         "limited_by": {"raster": "vector instruction issue (a SIMD takes 4 cycles per wave64 instruction at any occupancy, "
+                                                  "profiles/valu_rate.hip: valu_issue.valu_busy of the launch's cycles, with 0.59 of the lanes), "
                                                   "then the rate of scattered 64-bit atomics",
-                                        "shade": "dependent-load latency at four waves per SIMD, then the address unit (about 60 % busy)",
-                                        "shadow": "dependent-load latency and lane divergence of the tree walk"}.get(dom, "memory"),
+                                        "shade": "vector instruction issue (valu_issue.valu_busy of the launch's cycles), then the vector memory path",
+                                        "shadow": "vector instruction issue, then dependent-load latency of the tree walk"}.get(dom, "memory"),
                          "algorithmic_bytes": ab_dom, "kernel_ms": t_dom,
                          "frame_algorithmic_bytes": sum(ab.values()),
                          "frame_frac": sum(ab.values()) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -386,12 +388,11 @@ def main():
                 if peak > 0:
                     out["raster_atomics"].update({"peak": peak, "frac": st["fragments"] / raster_s / peak, "unit": "atomics/s",
                                                   "peak_source": "profiles/atomic_peak.hip, pattern box_2x2_region32, measured in this run"})
-                    # its two throughput limits side by side (share of the atomic ceiling, share of the vector issue slots from
-                    # the committed PMC record); neither is what sets the kernel's length on this workload: a build without the
-                    # atomic runs no faster (profiles/r3/raster_without_atomics.txt), the kernel is a chain of LDS and memory
-                    # round trips per meshlet with five waves per SIMD to hide it
+                    # its two throughput limits side by side: the share of the atomic ceiling, and the share of its cycles the
+                    # SIMDs spent issuing vector instructions (from the committed PMC record).  The second is the one the
+                    # kernel is at: a build without the atomic runs no faster (profiles/r3/raster_without_atomics.txt)
                     out["raster_atomics"]["valu_issue_frac"] = (raster_issue or {}).get("valu_busy")
-                    out["raster_atomics"]["limits"] = "latency per meshlet first; of the throughput limits the atomic rate is the nearer one"
+                    out["raster_atomics"]["limits"] = "vector instruction issue first, the atomic rate second"
             except Exception as e:  # the helper library is optional
                 out["raster_atomics"]["peak_error"] = str(e)
         if world == 1 and frame is None and args.secondary_frames > 0:

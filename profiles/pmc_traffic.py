@@ -6,9 +6,11 @@ bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB: both counters tally KiB, and FETCH_SI
 because gfx950 counts a 128-byte read request as 64 bytes.
 
 Also, from the sq3 and tcp passes, how close each kernel is to its instruction-issue bound:
-valu_busy = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): a gfx950 SIMD is 32 lanes wide
-and issues a wave64 vector instruction every 2 cycles when it has two or more waves to pick from (a single
-wave's stream issues one every 4), so this is the share of the chip's vector issue slots the launch used; and
+valu_busy = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): a SIMD of this chip takes 4 cycles
+per wave64 vector instruction however many waves it has to pick from (profiles/valu_rate.hip: 4.4 cycles per
+v_fma_f32 with one wave per SIMD, 3.9 - 4.1 with two to eight; a packed v_pk_fma_f32 takes the same 4 cycles for
+twice the arithmetic), so this is the share of the launch's cycles in which its SIMDs were issuing vector
+instructions -- a lower bound, transcendental and 64-bit instructions take longer; and
 lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU).
 """
 import csv
@@ -54,7 +56,7 @@ for k, c in sorted(issue_acc.items()):
     mean = lambda n: sum(c[n]) / len(c[n])
     if mean("GRBM_GUI_ACTIVE") <= 0 or mean("SQ_INSTS_VALU") <= 0:
         continue
-    issue[k] = {"valu_busy": round(mean("SQ_INSTS_VALU") * 2.0 / (1024.0 * mean("GRBM_GUI_ACTIVE") / 8.0), 3),
+    issue[k] = {"valu_busy": round(mean("SQ_INSTS_VALU") * 4.0 / (1024.0 * mean("GRBM_GUI_ACTIVE") / 8.0), 3),
                 "lane_utilisation": round(mean("SQ_THREAD_CYCLES_VALU") / (64.0 * mean("SQ_INSTS_VALU")), 3)}
 out = {
     "workload": workload,
@@ -62,7 +64,7 @@ out = {
             "(2*FETCH_SIZE + WRITE_SIZE) KiB; FETCH_SIZE doubled for gfx950's 64-B tally of 128-B reads; "
             "raster = the k_raster instantiations + k_mid_fill",
     "kernels": dict(sorted(merged.items())),
-    "issue_note": "valu_busy = SQ_INSTS_VALU * 2 cycles (SIMD-32: one wave64 instruction per 2 cycles) / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs); "
+    "issue_note": "valu_busy = SQ_INSTS_VALU * 4 cycles (a SIMD issues one wave64 vector instruction per 4 cycles at any occupancy: profiles/valu_rate.hip) / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs); "
                   "lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_INSTS_VALU) (passes sq3, tcp)",
     "issue": issue,
 }
