@@ -732,8 +732,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : 5
     MeshletOperands<MASK> next{};
     auto record = [&](uint32_t i) { return load_visible(fv.visible + (MASK ? fv.visible_capacity - 1u - i : i)); };
     // the loads of `next` have completed once their results have passed through here
+    // Which meshlets: the first two by the wave's place in the grid, every further one by a ticket drawn a meshlet
+    // ahead (FrameCounters::raster_ticket), so that waves with light meshlets take more of them.
+    const uint32_t n_segments = min(kRasterSegments, gridDim.x), segment = blockIdx.x % n_segments;
+    // (the counter's address through a lane offset the compiler cannot see is zero: with an address it knows to be
+    // uniform it rewrites the atomic into a form that reads the result back at once, and the wave would wait for the
+    // ticket, and for every fragment of the meshlet before, at the top of each pass)
+    uint32_t lane_zero = 0;
+    asm volatile("" : "+v"(lane_zero));
+    uint32_t* const ticket_counter = &fv.counters->raster_ticket[MASK ? 1 : 0][segment * 32u] + lane_zero;
+    uint32_t ticket = 0; // lane 0's is the one drawn
     auto settle = [&]() {
-        asm volatile("" : "+v"(next.px), "+v"(next.py), "+v"(next.pz), "+v"(next.tri_a), "+v"(next.tri_b), "+v"(next.model_lane));
+        asm volatile("" : "+v"(next.px), "+v"(next.py), "+v"(next.pz), "+v"(next.tri_a), "+v"(next.tri_b), "+v"(next.model_lane), "+v"(ticket));
         if constexpr (MASK) asm volatile("" : "+v"(next.uv.x), "+v"(next.uv.y), "+v"(next.uv.z), "+v"(next.uv.w));
     };
     if (blockIdx.x < vis_count) {
@@ -741,10 +751,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : 5
         fetch_meshlet<MASK>(sv, vm_next, lane, next);
     }
     settle();
-    for (uint32_t mi = blockIdx.x; mi < vis_count; mi += gridDim.x) {
+    uint32_t mi_next = blockIdx.x + gridDim.x;
+    for (uint32_t mi = blockIdx.x; mi < vis_count;) {
         const VisibleMeshlet vm = vm_next;
         const MeshletOperands<MASK> op = next;
-        const bool has_next = mi + gridDim.x < vis_count;
+        const bool has_next = mi_next < vis_count;
         m.vertex_offset = vm.vertex_offset; m.triangle_offset = vm.triangle_offset;
         m.vertex_count = vm.counts & 0xFFu; m.triangle_count = (vm.counts >> 16) & 0xFFu;
         const uint32_t mesh_vertex_offset = vm.mesh_vertex_offset;
@@ -755,7 +766,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : 5
 
         __syncthreads(); // previous meshlet's readers are done
         // (after the barrier: the barrier waits for the scalar unit's loads together with the LDS operations)
-        if (has_next) vm_next = record(mi + gridDim.x);
+        if (has_next) {
+            vm_next = record(mi_next);
+            if (lane == 0u) ticket = atomicAdd(ticket_counter, 1u); // for the meshlet after that one
+        }
         float model[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) model[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, op.model_lane), k));
@@ -827,6 +841,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : 5
         // the next meshlet's operands have arrived by now; taking them into registers here, before this meshlet's
         // atomics, keeps the wait for them from covering those atomics as well
         settle();
+        const uint32_t mi_after = 2u * gridDim.x + (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket) * n_segments + segment;
         // Triangle phase 2: set-up and scan of the queued triangles, one per lane
         for (uint32_t q0 = 0; q0 < n_queued; q0 += 64) {
             bool defer = false; // clipped, large or pixel-heavy triangles go to the tile path
@@ -1011,6 +1026,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : 5
                 }
             }
         }
+        mi = mi_next;
+        mi_next = mi_after;
     }
     if (fv.collect_stats) {
         uint32_t a = wave_sum(st_tested), b = wave_sum(st_raster), c = wave_sum(st_big), f = wave_sum(st_frags);
@@ -1959,6 +1976,7 @@ __global__ __launch_bounds__(256) void k_phase_reset(FrameView fv) {
     }
     if (gi < kMidSegments) fv.counters->mid_seg[gi * 32u] = 0u;
     if (gi < kFragSegments) fv.counters->frag_seg[gi * 16u] = 0ull;
+    if (gi < 2u * kRasterSegments) fv.counters->raster_ticket[gi / kRasterSegments][(gi % kRasterSegments) * 32u] = 0u;
 }
 
 __global__ __launch_bounds__(256) void k_clear(unsigned long long* vis, size_t n, FrameCounters* counters, uint32_t* tile_count,

@@ -139,11 +139,22 @@ struct FrameCounters {
     unsigned long long frag_seg[32 * 32]; // word s * 16: covered pixels (low half) and triangles (high half) of segment s
     uint32_t frag_overflow;
     uint32_t _pad_frag[31];
+    // k_raster's meshlet tickets (opaque list, alpha-tested list): a wave takes its first two meshlets by its place in
+    // the grid and draws a ticket for every further one.  The visible list is in scene order, so the meshlets a fixed
+    // stride hands a wave are a regular sample of the scene (every so-manyth instance of a row, say) and the waves'
+    // shares differ by a factor of two and more; with tickets a wave that got light meshlets simply takes more.  One
+    // counter would serialise (same-address atomics, about 10 ns each): ticket t of segment s is meshlet
+    // 2 * grid + t * segments + s, a wave uses segment blockIdx % segments, counters 128 bytes apart as above.
+#ifndef RDR_RASTER_SEGMENTS
+#define RDR_RASTER_SEGMENTS 128
+#endif
+    uint32_t raster_ticket[2][RDR_RASTER_SEGMENTS * 32];
 };
 constexpr uint32_t kTileJob = 8; // bin records per job of the tile rasteriser
 constexpr uint32_t kMidSegments = 32;
 constexpr uint32_t kFragSegments = 32;
-static_assert(sizeof(FrameCounters) == 192 + 4096 + 8192 + 128, "FrameCounters layout");
+constexpr uint32_t kRasterSegments = RDR_RASTER_SEGMENTS;
+static_assert(sizeof(FrameCounters) == 192 + 4096 + 8192 + 128 + 2 * RDR_RASTER_SEGMENTS * 128, "FrameCounters layout");
 
 struct GpuImage {
     uint32_t width, height, mip_count, format;
