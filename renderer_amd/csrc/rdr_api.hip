@@ -484,8 +484,13 @@ FrameView make_frame_view(rdr_renderer* r) {
     g.cull_blocks = std::max(1u, std::min((fv.command_capacity + 15u) / 16u, std::max(1u, r->resident.meshlet_cull)));
     g.raster_blocks = std::max(1u, std::min(fv.visible_capacity, std::max(1u, fv.touched ? r->resident.raster_touch : r->resident.raster)));
     g.raster_mask_blocks = std::max(1u, std::min(r->masked_meshlets, std::max(1u, fv.touched ? r->resident.raster_mask_touch : r->resident.raster_mask)));
-    // the tile rasteriser's workgroups take tiles from the list of non-empty ones: one resident round
-    g.deferred_blocks = std::max(1u, std::min(fv.tiles_x * fv.tiles_y, r->resident.tile_raster));
+    // the tile rasteriser's workgroups take jobs from the list a grid's width apart: one resident round, or four when
+    // the last finished frame had triangles for it, so that the hardware hands the later workgroups to whichever
+    // compute unit is done first (jobs differ a lot in what they cover; with one round the workgroups' ends were
+    // spread over half the kernel's length: interior scene 89 -> 79 us; an empty launch of four rounds costs 2 us more)
+    const uint32_t work_hint = r->status_host ? r->status_host[2] : 0u;
+    const uint32_t deferred_blocks_max = std::max(1u, std::min(fv.tiles_x * fv.tiles_y * 16u, 4u * r->resident.tile_raster));
+    g.deferred_blocks = (work_hint & 2u) ? deferred_blocks_max : std::max(1u, std::min(fv.tiles_x * fv.tiles_y * 16u, r->resident.tile_raster));
     g.mid_blocks = std::max(1u, r->resident.mid_raster);
     g.frag_blocks = r->masked_meshlets ? std::max(1u, r->resident.alpha_frag) : 1u;
     g.shade_blocks_x = (r->width + 15u) / 16u;
@@ -497,13 +502,13 @@ FrameView make_frame_view(rdr_renderer* r) {
     // beside another renderer's), a multiple of the queue segments; on when the last finished frame had no such work
     g.rare_blocks = r->tile_path_rare_mode ? (std::min(128u, r->resident.tile_path_rare) / 32u) * 32u : 0u;
     {
-        const uint32_t hint = r->status_host ? r->status_host[2] : 0u;
+        const uint32_t hint = work_hint;
         g.tile_path_rare = r->tile_path_rare_mode == 2u ? 1u : ((hint != 0u && (hint & 0xFFu) == 0u) ? 1u : 0u);
     }
     g.slot_mid = g.slot_raster + (g.raster_blocks + g.raster_mask_blocks) * kRasterSlots;
     g.slot_frag = g.slot_mid + std::max(g.mid_blocks, g.rare_blocks);
     g.slot_deferred = g.slot_frag + g.frag_blocks;
-    g.slot_shade = g.slot_deferred + std::max(g.deferred_blocks, g.rare_blocks);
+    g.slot_shade = g.slot_deferred + std::max(deferred_blocks_max, g.rare_blocks); // (the same from frame to frame: the slots are allocated once)
     g.slot_total = g.slot_shade;
     return fv;
 }

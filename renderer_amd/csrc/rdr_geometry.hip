@@ -1626,7 +1626,7 @@ RDR_DEV void pass_epilogue(const FrameView& fv, uint32_t block, uint32_t n_block
         flags |= (c->cmd_count > fv.command_capacity || (unsigned long long)c->vis_count + c->vis_mask_count > fv.visible_capacity)
                      ? RDR_FRAME_LIST_OVERFLOW : 0u;
         c->sticky_flags = flags;
-        uint32_t work = c->tile_work | (c->deferred_count ? 1u : 0u);
+        uint32_t work = c->tile_work | (c->deferred_count ? 3u : 0u); // bit 1: triangles for the tile rasteriser itself
         for (uint32_t sgm = 0; sgm < kMidSegments; ++sgm) work |= c->mid_seg[sgm * 32u] ? 1u : 0u;
         c->tile_work = work;
         __hip_atomic_store(&fv.host_status[0], (fv.frame_seq << 8) | flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

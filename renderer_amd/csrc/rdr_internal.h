@@ -437,7 +437,8 @@ struct FrameView {
     // Frame status in pinned host memory: word 0 is written by the last kernel of the geometry half, word 1 by
     // the last kernel of the shading half, each as frame_seq << 8 | RDR_FRAME_* flags, so that the host learns
     // of dropped work without synchronising (it looks at the words when the next frame is submitted).  Word 2:
-    // frame_seq << 8 | 1 when the frame had work for the tile path or the mid-sized queue (FrameCounters::tile_work).
+    // frame_seq << 8 | work: bit 0 when the frame had work for the tile path or the mid-sized queue, bit 1 when it had
+    // triangles for the tile rasteriser itself (FrameCounters::tile_work).
     uint32_t* host_status;
     uint32_t frame_seq;
     uint32_t convex_skip; // 1: shadow rays that leave a closed convex mesh skip that mesh (0 only as a measurement hook)
