@@ -358,12 +358,12 @@ def main():
             "roofline": {"kernel": "k_" + dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          # the contract's bound is HBM or MFMA; of the two this path can only meet HBM, but none of the three
-                         # large kernels is limited by bandwidth (valu_issue: share of its cycles the SIMDs spent issuing vector
-                         # instructions at 4 cycles each, and the lanes active in them)
-                         "limited_by": {"raster": "vector instruction issue (a SIMD takes 4 cycles per wave64 instruction at any occupancy, "
-                                                  "profiles/valu_rate.hip: valu_issue.valu_busy of the launch's cycles, with 0.59 of the lanes), "
-                                                  "then the rate of scattered 64-bit atomics",
-                                        "shade": "vector instruction issue (valu_issue.valu_busy of the launch's cycles), then the vector memory path",
+                         # large kernels is limited by bandwidth (valu_issue: the SIMD cycles the launch had per vector
+                         # instruction it issued, the busy share that is at the measured costs of an instruction, the lanes active)
+                         "limited_by": {"raster": "vector instruction issue (valu_issue: SIMD cycles per wave64 vector instruction against a cost of 2.3-2.8 "
+                                                  "cycles with register operands and 4.0-4.5 with a scalar operand, 64-bit, packed or cross-lane, "
+                                                  "profiles/valu_rate.hip; four waves per SIMD run it as fast as five), then the rate of scattered 64-bit atomics",
+                                        "shade": "vector instruction issue (valu_issue), then the vector memory path",
                                         "shadow": "vector instruction issue, then dependent-load latency of the tree walk"}.get(dom, "memory"),
                          "algorithmic_bytes": ab_dom, "kernel_ms": t_dom,
                          "frame_algorithmic_bytes": sum(ab.values()),
@@ -391,7 +391,7 @@ def main():
                     # its two throughput limits side by side: the share of the atomic ceiling, and the share of its cycles the
                     # SIMDs spent issuing vector instructions (from the committed PMC record).  The second is the one the
                     # kernel is at: a build without the atomic runs no faster (profiles/r3/raster_without_atomics.txt)
-                    out["raster_atomics"]["valu_issue_frac"] = (raster_issue or {}).get("valu_busy")
+                    out["raster_atomics"]["valu_issue_frac"] = [(raster_issue or {}).get("valu_busy_lo"), (raster_issue or {}).get("valu_busy_hi")]
                     out["raster_atomics"]["limits"] = "vector instruction issue first, the atomic rate second"
             except Exception as e:  # the helper library is optional
                 out["raster_atomics"]["peak_error"] = str(e)

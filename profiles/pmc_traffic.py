@@ -6,12 +6,13 @@ bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB: both counters tally KiB, and FETCH_SI
 because gfx950 counts a 128-byte read request as 64 bytes.
 
 Also, from the sq3 and tcp passes, how close each kernel is to its instruction-issue bound:
-valu_busy = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): a SIMD of this chip takes 4 cycles
-per wave64 vector instruction however many waves it has to pick from (profiles/valu_rate.hip: 4.4 cycles per
-v_fma_f32 with one wave per SIMD, 3.9 - 4.1 with two to eight; a packed v_pk_fma_f32 takes the same 4 cycles for
-twice the arithmetic), so this is the share of the launch's cycles in which its SIMDs were issuing vector
-instructions -- a lower bound, transcendental and 64-bit instructions take longer; and
-lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU).
+simd_cycles_per_valu = (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) / SQ_INSTS_VALU, the SIMD cycles the launch had for
+every wave64 vector instruction it issued, to be read against what an instruction costs (profiles/valu_rate.hip,
+profiles/r3/valu_rate.txt: 2.3 - 2.8 cycles with register operands and four or more waves to pick from, 4.0 - 4.5
+with a scalar-register operand, for 64-bit integer, packed fp32 and cross-lane instructions, 7.6 for a
+transcendental; a wave alone on its SIMD gets one in every 5 - 9); valu_busy_lo / valu_busy_hi price every
+instruction at 2.5 and at 4.2 cycles: the share of the launch's cycles in which its SIMDs were issuing vector
+instructions lies between the two; and lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU).
 """
 import csv
 import glob
@@ -56,7 +57,9 @@ for k, c in sorted(issue_acc.items()):
     mean = lambda n: sum(c[n]) / len(c[n])
     if mean("GRBM_GUI_ACTIVE") <= 0 or mean("SQ_INSTS_VALU") <= 0:
         continue
-    issue[k] = {"valu_busy": round(mean("SQ_INSTS_VALU") * 4.0 / (1024.0 * mean("GRBM_GUI_ACTIVE") / 8.0), 3),
+    per_valu = (1024.0 * mean("GRBM_GUI_ACTIVE") / 8.0) / mean("SQ_INSTS_VALU")
+    issue[k] = {"simd_cycles_per_valu": round(per_valu, 2),
+                "valu_busy_lo": round(min(1.0, 2.5 / per_valu), 3), "valu_busy_hi": round(min(1.0, 4.2 / per_valu), 3),
                 "lane_utilisation": round(mean("SQ_THREAD_CYCLES_VALU") / (64.0 * mean("SQ_INSTS_VALU")), 3)}
 out = {
     "workload": workload,
@@ -64,7 +67,9 @@ out = {
             "(2*FETCH_SIZE + WRITE_SIZE) KiB; FETCH_SIZE doubled for gfx950's 64-B tally of 128-B reads; "
             "raster = the k_raster instantiations + k_mid_fill",
     "kernels": dict(sorted(merged.items())),
-    "issue_note": "valu_busy = SQ_INSTS_VALU * 4 cycles (a SIMD issues one wave64 vector instruction per 4 cycles at any occupancy: profiles/valu_rate.hip) / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs); "
+    "issue_note": "simd_cycles_per_valu = (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs) / SQ_INSTS_VALU; a wave64 vector instruction costs a SIMD 2.3-2.8 cycles "
+                  "with register operands, 4.0-4.5 with a scalar-register operand or as a 64-bit, packed or cross-lane instruction, 7.6 as a transcendental "
+                  "(profiles/valu_rate.hip); valu_busy_lo / _hi price all of them at 2.5 / 4.2 cycles; "
                   "lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_INSTS_VALU) (passes sq3, tcp)",
     "issue": issue,
 }

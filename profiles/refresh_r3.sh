@@ -23,6 +23,7 @@ python3 profiles/pmc_summary.py $O/pmc_atrium > $O/pmc_atrium4k_summary.txt
 python3 profiles/pmc_traffic.py $O/pmc_field 1250 5 3840 2160 > $O/pmc_traffic.log
 cp profiles/pmc_traffic.json $O/pmc_traffic.json
 # the rasteriser's own ceiling, the split's balance, the default bench line, and a two-rank rehearsal on the one GPU
+timeout -k 10 120 profiles/valu_rate > $O/valu_rate.txt
 timeout -k 10 120 python3 profiles/atomic_peak.py > $O/atomic_peak.json
 timeout -k 10 500 python3 -u profiles/rank_alone.py --frames 20 --out $O/rank_alone.json > $O/rank_alone.txt 2>&1
 timeout -k 10 400 python3 bench.py > $O/bench_default_n1.json 2> $O/bench_default_n1.err
