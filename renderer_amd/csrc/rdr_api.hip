@@ -482,8 +482,8 @@ FrameView make_frame_view(rdr_renderer* r) {
     GridPlan& g = fv.grid;
     g.draw_blocks = std::max(1u, (r->sv.draw_count + 255u) / 256u);
     g.cull_blocks = std::max(1u, std::min((fv.command_capacity + 15u) / 16u, std::max(1u, r->resident.meshlet_cull)));
-    g.raster_blocks = std::max(1u, std::min(fv.visible_capacity, std::max(1u, fv.touched ? r->resident.raster_touch : r->resident.raster)));
-    g.raster_mask_blocks = std::max(1u, std::min(r->masked_meshlets, std::max(1u, fv.touched ? r->resident.raster_mask_touch : r->resident.raster_mask)));
+    g.raster_blocks = std::max(1u, std::min(fv.visible_capacity, std::max(1u, r->resident.raster)));
+    g.raster_mask_blocks = std::max(1u, std::min(r->masked_meshlets, std::max(1u, r->resident.raster_mask)));
     // the tile rasteriser's workgroups take jobs from the list a grid's width apart: one resident round, or four when
     // the last finished frame had triangles for it, so that the hardware hands the later workgroups to whichever
     // compute unit is done first (jobs differ a lot in what they cover; with one round the workgroups' ends were
@@ -824,7 +824,7 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
         const size_t n_def = (size_t)std::min<uint64_t>(std::max<uint64_t>(tri_total, 1u << 16), 1u << 22);
         // mid queue: k_raster's opaque mid-sized triangles plus the alpha-tested ones k_tile_setup passes on from
         // the deferred list (its 1024 workgroups take deferred triangles a grid apart: n_def / 32 + 32 per segment)
-        const size_t n_mid = (size_t)std::min<uint64_t>(32 * (std::max(segment_worst(vis_cap, r->resident.raster), segment_worst(vis_cap, r->resident.raster_touch)) + n_def / 32 + 32), (uint64_t)2 << 22);
+        const size_t n_mid = (size_t)std::min<uint64_t>(32 * (segment_worst(vis_cap, r->resident.raster) + n_def / 32 + 32), (uint64_t)2 << 22);
         if (r->deferred.alloc(n_def) || r->setup.alloc(n_def + n_def / 2) || r->setup_mask.alloc(n_def + n_def / 2) ||
             r->mid.alloc(n_mid) || r->mid_mask.alloc(n_mid)) return 1;
         if (r->bin_entries.alloc(std::max<size_t>(n_def * 4, (size_t)1 << 22))) return 1;
@@ -832,7 +832,7 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
         if (r->tile_list.alloc(((size_t)r->tile_count.count / 2 + r->bin_entries.count / kTileJob + 1) * 4)) return 1; // x parts per tile
         // small alpha-tested triangles and their covered pixels (at most 16 each): every LOD-0 triangle of the
         // alpha-tested draws, capped like the lists above
-        const size_t n_frag = (size_t)std::min<uint64_t>(std::max<uint64_t>(32 * std::max(segment_worst(r->masked_meshlets, r->resident.raster_mask), segment_worst(r->masked_meshlets, r->resident.raster_mask_touch)), 1u << 12), 1u << 22);
+        const size_t n_frag = (size_t)std::min<uint64_t>(std::max<uint64_t>(32 * segment_worst(r->masked_meshlets, r->resident.raster_mask), 1u << 12), 1u << 22);
         if (r->frag_tri.alloc(n_frag) || r->frag_px.alloc(n_frag * 16)) return 1;
         // zeroed once: a consumer that meets a never-written entry (only possible after an overflow, which is
         // reported as an error) then reads a valid index

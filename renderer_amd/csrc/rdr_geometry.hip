@@ -47,7 +47,10 @@ RDR_DEV void stat_store(const FrameView& fv, uint32_t slot, uint32_t v) {
 // by a pixel, the pyramid level is chosen so that the box touches at most 2 x 2 texels, all of
 // which are read, and only a sphere whose nearest depth is strictly below the block minimum
 // is reported.  Spheres that reach the near plane are never reported.
-RDR_DEV bool sphere_occluded(const FrameView& fv, vec3 c, float r) {
+// The pixel box [ix0, ix1] x [iy0, iy1] that holds everything inside the view-space sphere (c, r), padded and widened
+// as described above and clipped to the frame (ix0 > ix1 or iy0 > iy1: nothing on screen); `r` comes back padded.
+// False when the sphere reaches the near plane or the box is not a number: no statement.
+RDR_DEV bool sphere_screen_box(const FrameView& fv, vec3 c, float& r, int& ix0, int& ix1, int& iy0, int& iy1) {
     const rdr_ubo& u = fv.ubo;
     r = r * 1.015625f + fabsf(c.z) * 0.0009765625f;
     if (!(c.z > r + u.near_plane)) return false;
@@ -61,8 +64,15 @@ RDR_DEV bool sphere_occluded(const FrameView& fv, vec3 c, float r) {
     const float ya = (0.5f - ay * u.proj[5] * 0.5f) * H, yb = (0.5f - by * u.proj[5] * 0.5f) * H;
     const float x_lo = fminf(xa, xb), x_hi = fmaxf(xa, xb), y_lo = fminf(ya, yb), y_hi = fmaxf(ya, yb);
     if (!(x_lo <= x_hi) || !(y_lo <= y_hi)) return false; // NaN: no statement
-    const int ix0 = max((int)floorf(clampf(x_lo, -4.0f, W + 4.0f)) - 1, 0), ix1 = min((int)floorf(clampf(x_hi, -4.0f, W + 4.0f)) + 1, (int)fv.width - 1);
-    const int iy0 = max((int)floorf(clampf(y_lo, -4.0f, H + 4.0f)) - 1, 0), iy1 = min((int)floorf(clampf(y_hi, -4.0f, H + 4.0f)) + 1, (int)fv.height - 1);
+    ix0 = max((int)floorf(clampf(x_lo, -4.0f, W + 4.0f)) - 1, 0); ix1 = min((int)floorf(clampf(x_hi, -4.0f, W + 4.0f)) + 1, (int)fv.width - 1);
+    iy0 = max((int)floorf(clampf(y_lo, -4.0f, H + 4.0f)) - 1, 0); iy1 = min((int)floorf(clampf(y_hi, -4.0f, H + 4.0f)) + 1, (int)fv.height - 1);
+    return true;
+}
+
+RDR_DEV bool sphere_occluded(const FrameView& fv, vec3 c, float r) {
+    const rdr_ubo& u = fv.ubo;
+    int ix0, ix1, iy0, iy1;
+    if (!sphere_screen_box(fv, c, r, ix0, ix1, iy0, iy1)) return false;
     if (ix0 > ix1 || iy0 > iy1) return false; // off screen: the frustum tests decide
     const uint32_t span = (uint32_t)max(ix1 - ix0, iy1 - iy0) + 1u;
     // smallest level whose texels (2^(l+1) pixels) are at least `span` wide: the box then touches <= 2 per axis
@@ -103,6 +113,10 @@ __global__ __launch_bounds__(256) void k_draw_cull(SceneView sv, FrameView fv) {
     const uint32_t di = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = lane_id();
     const rdr_ubo& u = fv.ubo;
+    // The sort-last tile flags start the frame at zero.  Here, in the frame's first kernel: the next one, the
+    // meshlet cull, already sets them.
+    if (PHASE != kPhaseLate && fv.touched)
+        for (uint32_t i = di; i < fv.touched_count; i += gridDim.x * blockDim.x) fv.touched[i] = 0u;
 
     uint32_t ncmd = 0, k_lo = 0, k_hi = 0, lod_meshlet_offset = 0, vis_off = 0, was_visible = 0, replicated = 0;
     float max_scale = 0.0f;
@@ -212,8 +226,6 @@ __global__ __launch_bounds__(256) void k_draw_cull(SceneView sv, FrameView fv) {
 // consecutive threads on consecutive addresses.
 constexpr uint32_t kClearPerThread = 4;
 RDR_DEV void clear_visbuffer(const FrameView& fv, uint32_t block, uint32_t blocks) {
-    if (fv.touched) // the sort-last tile flags share the buffer's life
-        for (uint32_t i = block * 1024u + threadIdx.x; i < fv.touched_count; i += blocks * 1024u) fv.touched[i] = 0u;
     const size_t n = (size_t)fv.width * fv.height;
     const size_t base = (size_t)block * (1024u * kClearPerThread) + threadIdx.x;
 #pragma unroll
@@ -251,6 +263,8 @@ __global__ __launch_bounds__(1024) void k_meshlet_cull(SceneView sv, FrameView f
         uint32_t draw_id = 0, first = 0, instance_first = 0, tri_count = 0, count = 0, masked = 0;
         uint32_t model_index = 0, mesh_vertex_offset = 0, m_vertex_offset = 0, m_triangle_offset = 0, m_counts = 0, replicated = 0;
         bool emit = false;
+        vec3 touch_centre = mk3(0.0f, 0.0f, 0.0f); // the meshlet's bounding sphere in view space
+        float touch_radius = 0.0f;
         if (ci < cmd_count) {
             // the command and everything it leads to is the same for the whole wave: read through the scalar unit
             const auto* cp = &uniform_ref(&fv.commands[__builtin_amdgcn_readfirstlane(ci)]);
@@ -278,6 +292,7 @@ __global__ __launch_bounds__(1024) void k_meshlet_cull(SceneView sv, FrameView f
                 const vec4 av = mul_m4(u.view, aw);
                 const vec3 axis = normalize3(mk3(av.x, av.y, av.z));
                 const float radius = max_scale * m.radius;
+                touch_centre = cc; touch_radius = radius;
                 const float cutoff = (float)m.cone_cutoff / 127.0f;
                 accept = accept && !(dot3(cc, axis) >= cutoff * len3(cc) + radius);
                 accept = accept && (cc.z * -u.frustum[1] + cc.x * u.frustum[0] < radius);
@@ -305,6 +320,28 @@ __global__ __launch_bounds__(1024) void k_meshlet_cull(SceneView sv, FrameView f
             }
         }
         accept = emit;
+        // Sort-last tile flags for what k_raster's lanes will scan of this meshlet: every tile under the screen box of
+        // its bounding sphere (all its vertices are inside, so are the pixels of a triangle whose three corners need
+        // no clipping; the other triangles go to kernels that mark for themselves).  Here and not in k_raster, where
+        // the box of the 64 transformed vertices costs four wave-wide reductions per meshlet (a fifth of the kernel);
+        // a meshlet whose sphere reaches the near plane or covers more than nine tiles is left to that (bit 30 of its
+        // record's counts).
+        if (fv.touched && accept) {
+            int ix0, ix1, iy0, iy1;
+            float padded = touch_radius;
+            bool marked = false;
+            if (sphere_screen_box(fv, touch_centre, padded, ix0, ix1, iy0, iy1)) {
+                marked = true;
+                if (ix0 <= ix1 && iy0 <= iy1) {
+                    const uint32_t tx0 = (uint32_t)ix0 / kTouchTile, tx1 = (uint32_t)ix1 / kTouchTile, ty0 = (uint32_t)iy0 / kTouchTile, ty1 = (uint32_t)iy1 / kTouchTile;
+                    marked = (tx1 - tx0 + 1u) * (ty1 - ty0 + 1u) <= 9u; // a lane's worth; a meshlet that fills the screen has a wave there
+                    if (marked)
+                        for (uint32_t ty = ty0; ty <= ty1; ++ty)
+                            for (uint32_t tx = tx0; tx <= tx1; ++tx) fv.touched[ty * fv.touched_x + tx] = 1u;
+                }
+            }
+            if (!marked) m_counts |= 0x40000000u;
+        }
         const unsigned long long mask = __ballot(accept);
         const uint32_t n_acc = (uint32_t)__popcll(mask);
         if (lane == 0) { wave_count[wave] = n_acc; wave_masked[wave] = masked; }
@@ -708,10 +745,10 @@ RDR_DEV void fetch_meshlet(const SceneView& sv, const VisibleMeshlet& r, uint32_
 // MASK = false: meshlets of opaque draws (front of the visible list); MASK = true:
 // meshlets of alpha-tested draws (back of the list).  Two instantiations so that the
 // opaque one carries no uv / texture state in registers.
-// TOUCH: keep the sort-last tile flags (an instantiation of its own: the few registers the marking needs would
-// cost the plain opaque one its fifth wave per SIMD).
+// TOUCH: keep the sort-last tile flags for the meshlets k_meshlet_cull left to this kernel (an instantiation of its
+// own: even never taken, the marking costs the plain one 2 %).
 template <bool MASK, bool TOUCH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : 5))) void k_raster(SceneView sv, FrameView fv) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 4 : 5))) void k_raster(SceneView sv, FrameView fv) {
     __shared__ MeshletLds lds;
     __shared__ MaskVertexLds<MASK> mlds;
     const uint32_t lane = threadIdx.x;
@@ -802,7 +839,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 3 : 5
         // phases then skip the per-corner reads that would tell them so (wave-uniform branches).
         const bool any_behind = __ballot(vert_behind) != 0ull, any_clipped = __ballot(vert_clipped) != 0ull;
         __syncthreads();
-        if (TOUCH) touch_meshlet(fv, lane < m.vertex_count && lds.clip[lane] == 0u, lds.X, lds.Y, lane);
+        // sort-last tile flags: k_meshlet_cull has marked the tiles under the meshlet's bounding sphere, unless that
+        // reaches the near plane or is large on screen (bit 30 of the record's counts: the same in the whole wave)
+        if (TOUCH && (vm.counts & 0x40000000u)) touch_meshlet(fv, lane < m.vertex_count && lds.clip[lane] == 0u, lds.X, lds.Y, lane);
         if (has_next) fetch_meshlet<MASK>(sv, vm_next, lane, next); // in flight during the cull tests
 
         // Triangle phase 1: the mesh shader's cull tests, two triangles per lane; the survivors (about
@@ -2021,14 +2060,11 @@ int rdr_geometry_residency(GeometryResidency* out, uint32_t fill_lds_bytes) {
     RDR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
     RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_meshlet_cull<kPhaseLate>, 1024, 0));
     out->meshlet_cull = (uint32_t)(n * cus);
+    // (the instantiations that keep the sort-last tile flags are held to the same register budgets)
     RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (k_raster<false, false>), 64, 0));
     out->raster = (uint32_t)(n * cus);
     RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (k_raster<true, false>), 64, 0));
     out->raster_mask = (uint32_t)(n * cus);
-    RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (k_raster<false, true>), 64, 0));
-    out->raster_touch = (uint32_t)(n * cus);
-    RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (k_raster<true, true>), 64, 0));
-    out->raster_mask_touch = (uint32_t)(n * cus);
     RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_mid_fill, 256, fill_lds_bytes));
     out->mid_raster = (uint32_t)(n * cus);
     RDR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_alpha_frag, 256, 0));

@@ -503,7 +503,6 @@ int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t st
 struct GeometryResidency {
     uint32_t meshlet_cull, raster, raster_mask, mid_raster, alpha_frag, tile_raster; // resident workgroups on the whole device
     uint32_t tile_path_rare; // k_tile_path_rare (0: does not fit, e.g. its LDS at this frame size)
-    uint32_t raster_touch, raster_mask_touch; // k_raster's instantiations that keep the sort-last tile flags
 };
 int rdr_geometry_residency(GeometryResidency* out, uint32_t fill_lds_bytes);
 // Dynamic LDS of k_mid_fill: one bin offset per 64x64 tile and the 256 partial sums of its prefix sum.
