@@ -121,10 +121,15 @@ __global__ __launch_bounds__(256) void k_draw_cull(SceneView sv, FrameView fv) {
     uint32_t ncmd = 0, k_lo = 0, k_hi = 0, lod_meshlet_offset = 0, vis_off = 0, was_visible = 0, replicated = 0;
     float max_scale = 0.0f;
     bool emitted = false;
+    uint32_t draw_model_index = 0, draw_mesh_vertex_offset = 0;
+    bool draw_masked = false;
     if (di < sv.draw_count) {
         const rdr_mesh_draw d = sv.draws[di];
         if (PHASE != kPhaseSingle) was_visible = fv.draw_visible[di];
         const rdr_mesh* mesh = &sv.meshes[d.mesh_index];
+        draw_model_index = d.model_index;
+        draw_mesh_vertex_offset = mesh->vertex_offset;
+        draw_masked = d.alpha_mode == 1u;
         float model[16];
         load_m4(sv.transforms + (size_t)d.model_index * 16, model);
         const vec4 cw = mul_m4(model, mk4(mesh->center[0], mesh->center[1], mesh->center[2], 1.0f));
@@ -202,9 +207,9 @@ __global__ __launch_bounds__(256) void k_draw_cull(SceneView sv, FrameView fv) {
                 cmd.count = min(64u, b - k);
                 cmd.instance_first = vis_off + k;
                 cmd.max_scale = max_scale;
-                cmd.late_draw_visibility = was_visible;
-                cmd.replicated = replicated;
-                cmd._pad = 0;
+                cmd.flags = (was_visible ? kCmdLateVisible : 0u) | (replicated ? kCmdReplicated : 0u) | (draw_masked ? kCmdMasked : 0u);
+                cmd.model_index = draw_model_index;
+                cmd.mesh_vertex_offset = draw_mesh_vertex_offset;
                 fv.commands[slot] = cmd;
             }
         });
@@ -240,7 +245,7 @@ RDR_DEV void clear_visbuffer(const FrameView& fv, uint32_t block, uint32_t block
 }
 
 template <int PHASE>
-__global__ __launch_bounds__(1024) void k_meshlet_cull(SceneView sv, FrameView fv) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void k_meshlet_cull(SceneView sv, FrameView fv) {
     __shared__ uint32_t wave_count[16];
     __shared__ uint32_t wave_masked[16];
     __shared__ uint32_t wg_base[2];
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(1024) void k_meshlet_cull(SceneView sv, FrameView f
         return;
     }
     const uint32_t lane = lane_id();
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // the same in the whole wave, and known to be
     const rdr_ubo& u = fv.ubo;
     const uint32_t cmd_count = min(fv.counters->cmd_count, fv.command_capacity);
 
@@ -263,19 +268,17 @@ __global__ __launch_bounds__(1024) void k_meshlet_cull(SceneView sv, FrameView f
         uint32_t draw_id = 0, first = 0, instance_first = 0, tri_count = 0, count = 0, masked = 0;
         uint32_t model_index = 0, mesh_vertex_offset = 0, m_vertex_offset = 0, m_triangle_offset = 0, m_counts = 0, replicated = 0;
         bool emit = false;
-        vec3 touch_centre = mk3(0.0f, 0.0f, 0.0f); // the meshlet's bounding sphere in view space
-        float touch_radius = 0.0f;
         if (ci < cmd_count) {
             // the command and everything it leads to is the same for the whole wave: read through the scalar unit
             const auto* cp = &uniform_ref(&fv.commands[__builtin_amdgcn_readfirstlane(ci)]);
             draw_id = cp->draw_id; first = cp->meshlet_first; count = cp->count;
             instance_first = cp->instance_first;
-            replicated = cp->replicated;
+            const uint32_t cmd_flags = cp->flags;
+            replicated = (cmd_flags & kCmdReplicated) ? 1u : 0u;
             const float max_scale = cp->max_scale;
-            const auto& d = uniform_ref(&sv.draws[draw_id]);
-            model_index = d.model_index;
-            mesh_vertex_offset = uniform_ref(&sv.meshes[d.mesh_index]).vertex_offset;
-            masked = d.alpha_mode == 1u ? 1u : 0u;
+            model_index = cp->model_index;
+            mesh_vertex_offset = cp->mesh_vertex_offset;
+            masked = (cmd_flags & kCmdMasked) ? 1u : 0u;
             float model[16];
             load_m4_uniform(sv.transforms + (size_t)model_index * 16, model);
             accept = lane < count;
@@ -292,7 +295,6 @@ __global__ __launch_bounds__(1024) void k_meshlet_cull(SceneView sv, FrameView f
                 const vec4 av = mul_m4(u.view, aw);
                 const vec3 axis = normalize3(mk3(av.x, av.y, av.z));
                 const float radius = max_scale * m.radius;
-                touch_centre = cc; touch_radius = radius;
                 const float cutoff = (float)m.cone_cutoff / 127.0f;
                 accept = accept && !(dot3(cc, axis) >= cutoff * len3(cc) + radius);
                 accept = accept && (cc.z * -u.frustum[1] + cc.x * u.frustum[0] < radius);
@@ -314,34 +316,34 @@ __global__ __launch_bounds__(1024) void k_meshlet_cull(SceneView sv, FrameView f
                             else atomicAnd(word, ~bit);
                         }
                         // already drawn by the early phase: its draw was visible and its bit was set
-                        emit = accept && !(cp->late_draw_visibility != 0u && was && !masked);
+                        emit = accept && !((cmd_flags & kCmdLateVisible) && was && !masked);
                     }
+                }
+                // Sort-last tile flags for what k_raster's lanes will scan of this meshlet: every tile under the screen box of
+                // its bounding sphere (all its vertices are inside, so are the pixels of a triangle whose three corners need
+                // no clipping; the other triangles go to kernels that mark for themselves).  Here and not in k_raster, where
+                // the box of the 64 transformed vertices costs four wave-wide reductions per meshlet (a fifth of the kernel);
+                // a meshlet whose sphere reaches the near plane or covers more than nine tiles is left to that (bit 30 of its
+                // record's counts).
+                if (fv.touched && emit) {
+                    int ix0, ix1, iy0, iy1;
+                    float padded = radius;
+                    bool marked = false;
+                    if (sphere_screen_box(fv, cc, padded, ix0, ix1, iy0, iy1)) {
+                        marked = true;
+                        if (ix0 <= ix1 && iy0 <= iy1) {
+                            const uint32_t tx0 = (uint32_t)ix0 / kTouchTile, tx1 = (uint32_t)ix1 / kTouchTile, ty0 = (uint32_t)iy0 / kTouchTile, ty1 = (uint32_t)iy1 / kTouchTile;
+                            marked = (tx1 - tx0 + 1u) * (ty1 - ty0 + 1u) <= 9u; // a lane's worth; a meshlet that fills the screen has a wave there
+                            if (marked)
+                                for (uint32_t ty = ty0; ty <= ty1; ++ty)
+                                    for (uint32_t tx = tx0; tx <= tx1; ++tx) fv.touched[ty * fv.touched_x + tx] = 1u;
+                        }
+                    }
+                    if (!marked) m_counts |= 0x40000000u;
                 }
             }
         }
         accept = emit;
-        // Sort-last tile flags for what k_raster's lanes will scan of this meshlet: every tile under the screen box of
-        // its bounding sphere (all its vertices are inside, so are the pixels of a triangle whose three corners need
-        // no clipping; the other triangles go to kernels that mark for themselves).  Here and not in k_raster, where
-        // the box of the 64 transformed vertices costs four wave-wide reductions per meshlet (a fifth of the kernel);
-        // a meshlet whose sphere reaches the near plane or covers more than nine tiles is left to that (bit 30 of its
-        // record's counts).
-        if (fv.touched && accept) {
-            int ix0, ix1, iy0, iy1;
-            float padded = touch_radius;
-            bool marked = false;
-            if (sphere_screen_box(fv, touch_centre, padded, ix0, ix1, iy0, iy1)) {
-                marked = true;
-                if (ix0 <= ix1 && iy0 <= iy1) {
-                    const uint32_t tx0 = (uint32_t)ix0 / kTouchTile, tx1 = (uint32_t)ix1 / kTouchTile, ty0 = (uint32_t)iy0 / kTouchTile, ty1 = (uint32_t)iy1 / kTouchTile;
-                    marked = (tx1 - tx0 + 1u) * (ty1 - ty0 + 1u) <= 9u; // a lane's worth; a meshlet that fills the screen has a wave there
-                    if (marked)
-                        for (uint32_t ty = ty0; ty <= ty1; ++ty)
-                            for (uint32_t tx = tx0; tx <= tx1; ++tx) fv.touched[ty * fv.touched_x + tx] = 1u;
-                }
-            }
-            if (!marked) m_counts |= 0x40000000u;
-        }
         const unsigned long long mask = __ballot(accept);
         const uint32_t n_acc = (uint32_t)__popcll(mask);
         if (lane == 0) { wave_count[wave] = n_acc; wave_masked[wave] = masked; }

@@ -37,11 +37,16 @@ struct CullCommand {
     uint32_t count;          // 1..64
     uint32_t instance_first; // meshlet-instance id of lane 0
     float max_scale;         // largest column length of the draw's model matrix
-    uint32_t late_draw_visibility; // occlusion culling, late phase: the draw was visible last frame (so its
-                                   // meshlets with their bit set were already drawn by the early phase)
-    uint32_t replicated;           // sort-last: every rank draws this draw (FrameView::replicate_pixels)
-    uint32_t _pad;
+    uint32_t flags;          // kCmd* below
+    // what the meshlet cull needs of the draw and its mesh, so that a command leads straight to the model matrix and
+    // the meshlets (two dependent loads fewer in front of every wave's tests)
+    uint32_t model_index;
+    uint32_t mesh_vertex_offset;
 };
+// kCmdLateVisible: occlusion culling, late phase: the draw was visible last frame (so its meshlets with their bit
+// set were already drawn by the early phase); kCmdReplicated: sort-last, every rank draws this draw
+// (FrameView::replicate_pixels); kCmdMasked: the draw is alpha-tested.
+constexpr uint32_t kCmdLateVisible = 1u, kCmdReplicated = 2u, kCmdMasked = 4u;
 static_assert(sizeof(CullCommand) == 32, "CullCommand must be 32 bytes");
 
 // A meshlet that survived culling, input of the rasteriser.
