@@ -461,10 +461,10 @@ RDR_DEV bool vert_needs_clip(float x, float y, float z, float w) {
 RDR_DEV void touch_pixel(const FrameView& fv, int px, int py) {
     if (fv.touched) fv.touched[(uint32_t)py / kTouchTile * fv.touched_x + (uint32_t)px / kTouchTile] = 1u;
 }
-// k_raster marks per meshlet, outside its triangle loop (in there the flags would cost the opaque instantiation
-// a wave per SIMD): every tile under the pixel box of the meshlet's vertices that need no clipping.  Triangles
-// scanned by a lane have three such vertices, so their pixels lie inside; the others go to kernels that mark
-// for themselves.  (X, Y): the lane's snapped 24.8 vertex, `valid`: it has one.
+// What k_raster's lanes scan is marked per meshlet: by k_meshlet_cull from the bounding sphere where that says enough,
+// else here, outside the triangle loop: every tile under the pixel box of the meshlet's vertices that need no
+// clipping.  Triangles scanned by a lane have three such vertices, so their pixels lie inside; the others go to
+// kernels that mark for themselves.  (X, Y): the lane's snapped 24.8 vertex, `valid`: it has one.
 // Wave-wide minimum as a scalar: four butterfly steps inside each row of 16 lanes on the data-parallel
 // path (no LDS round trips, one temporary), then the four rows through scalar registers.
 RDR_DEV int32_t wave_min_scalar(int32_t v) {
@@ -478,7 +478,7 @@ RDR_DEV int32_t wave_min_scalar(int32_t v) {
 
 RDR_DEV void touch_meshlet(const FrameView& fv, bool valid, const int32_t* lds_x, const int32_t* lds_y, uint32_t lane) {
     const int32_t big = 0x7FFFFFFF;
-    // one coordinate at a time: what is live here decides whether the kernel keeps its fifth wave per SIMD
+    // one coordinate at a time: few registers live at once
     int32_t v = lds_x[lane];
     const int32_t x0 = wave_min_scalar(valid ? v : big), x1 = -wave_min_scalar(valid ? -v : big);
     if (x0 > x1) return; // no usable vertex
@@ -1641,7 +1641,7 @@ __global__ __launch_bounds__(256) void k_mid_fill(SceneView sv, FrameView fv) {
 // records ... -> keys), which only other workgroups on the same CU can hide, and because a tile under many
 // large alpha-tested triangles would otherwise set the kernel's length alone (interior scene: one
 // 256-thread workgroup per tile with 4 x 4 pixels per thread 0.175 ms for the tile path, this 0.128 ms).
-// A frame with empty bins pays for the resident round only.
+// A frame with empty bins pays for the launch of one resident round only.
 // What the last kernel of a geometry pass owes the frame besides its own work: the sets of list heads and tile
 // counts the next frame will use are zeroed (FrameView::counters_next; spread over the grid), and the pass's status
 // goes where the host sees it without a synchronisation.  Every producer of the lists has finished (earlier
@@ -2054,8 +2054,9 @@ __global__ __launch_bounds__(256) void k_resolve(SceneView sv, FrameView fv, uin
 
 } // namespace
 
-// Workgroups of each persistent kernel that are resident at once on the current device:
-// their grids are sized to exactly one resident round, so no workgroup waits for a slot.
+// Workgroups of each persistent kernel that are resident at once on the current device: their grids are sized
+// to one resident round, so no workgroup waits for a slot (the tile rasteriser's to four when it has work: its
+// jobs are uneven, and the hardware then hands the later workgroups to whichever compute unit is free).
 int rdr_geometry_residency(GeometryResidency* out, uint32_t fill_lds_bytes) {
     int device = 0, cus = 0, n = 0;
     RDR_HIP(hipGetDevice(&device));
