@@ -660,6 +660,20 @@ def test_errors():
     assert g.read_color().shape == (36, 64, 4)
 
 
+@pytest.mark.parametrize("occlusion", [False, True])
+def test_bench_scene_at_low_resolution(oracle, occlusion):
+    """The scene the benchmark times (1250 instances, 164 000 visible meshlets: far more than the rasteriser's
+    resident waves take by their place in the grid, so nearly all of them are handed out by ticket, in both
+    phases of a frame with occlusion culling) at a resolution the CPU check renders in a blink: same keys,
+    same work counters, same colours."""
+    sc = synth.make_field(1250, 5, lods=1, with_env=True, prepared=True)
+    o, ovis, g = both(oracle, sc, 480, 270, lod_enabled=False, cull_enabled=occlusion)
+    check_vis(o, ovis, g)
+    check_color(o, g)
+    assert g.frame_status() == 0
+    g.close()
+
+
 def test_full_size_properties():
     """At the benchmark's size the oracle is too slow to run in a test; check size-independent
     properties instead, on the scene the benchmark times (meshlets from the library's mesh preparation):
