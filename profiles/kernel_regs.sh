@@ -3,6 +3,11 @@
 #   profiles/kernel_regs.sh rdr_geometry.hip [extra compiler flags]
 cd "$(dirname "$0")/../renderer_amd/csrc" || exit 1
 src="$1"; shift
+# the flags the Makefile gives the file on top of the common ones
+case "$src" in
+  rdr_shade.hip) set -- -fno-slp-vectorize -fno-hip-fp32-correctly-rounded-divide-sqrt -DRDR_FAST_DIVISION "$@" ;;
+  rdr_shadow.hip) set -- -fno-slp-vectorize "$@" ;;
+esac
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math --cuda-device-only \
     -Rpass-analysis=kernel-resource-usage "$@" -c "$src" -o /dev/null 2>&1 |
   awk '/Function Name:/ {name=$0; sub(/.*Function Name: /,"",name); sub(/ \[-Rpass.*/,"",name)}
