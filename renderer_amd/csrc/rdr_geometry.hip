@@ -827,7 +827,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 4 : 5
             int32_t X = 0, Y = 0;
             if (!nc) project_xy(clip.x, clip.y, rw, half_w, half_h, X, Y);
             lds.X[lane] = X; lds.Y[lane] = Y;
-            lds.clip[lane] = nc ? 1u : 0u;
+            // what the clipper's five planes say about the vertex (plane_dist < 0, the same expressions), bit 5: it needs clipping
+            uint32_t outside = 0u;
+            if (nc) {
+                const float g = kGuardBand * clip.w;
+                outside = 32u | (clip.w - clip.z < 0.0f ? 1u : 0u) | (g - clip.x < 0.0f ? 2u : 0u) | (g + clip.x < 0.0f ? 4u : 0u) |
+                          (g - clip.y < 0.0f ? 8u : 0u) | (g + clip.y < 0.0f ? 16u : 0u);
+            }
+            lds.clip[lane] = outside;
             vert_clipped = nc;
             if constexpr (MASK) {
                 if (at.has_tex) { // perspective-correct uv for the alpha test
@@ -913,8 +920,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MASK ? 4 : 5
             if (q0 + lane < n_queued) {
                 const uint32_t packed = lds.queue[q0 + lane];
                 ia = packed & 255u; ib = (packed >> 8) & 255u; ic = (packed >> 16) & 255u; ti = packed >> 24;
-                if (any_clipped) defer = (lds.clip[ia] | lds.clip[ib] | lds.clip[ic]) != 0u;
-                if (!defer) {
+                bool nothing_left = false;
+                if (any_clipped) {
+                    const uint32_t oa = lds.clip[ia], ob = lds.clip[ib], oc = lds.clip[ic];
+                    defer = (oa | ob | oc) != 0u;
+                    // all three corners outside one of the clipper's planes: it would leave nothing (geometry beside and
+                    // behind the camera, which the culling's spheres let through in bulk), so the triangle ends here
+                    nothing_left = (oa & ob & oc & 31u) != 0u;
+                    defer = defer && !nothing_left;
+                }
+                if (!defer && !nothing_left) {
                     // all nine reads at once: one LDS round trip in front of the set-up instead of two
                     const int32_t X0 = lds.X[ia], X1 = lds.X[ib], X2 = lds.X[ic];
                     const int32_t Y0 = lds.Y[ia], Y1 = lds.Y[ib], Y2 = lds.Y[ic];
