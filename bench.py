@@ -108,6 +108,7 @@ def secondary_series(W, H, frames, instances, subdivisions):
                     "Mtri_per_s_rasterised": st["triangles_rasterised"] / dt / 1e6,
                     "fragments": st["fragments"], "pixels_covered": st["pixels_covered"]})
         r.close()
+    out.append(camera_path_series(W, H, instances, subdivisions))
     # throughput with two frames in flight, as the reference's frame loop keeps up to three
     # (renderer/src/renderer.rs:919-922): two renderers take turns, each on its own stream
     scene = synth.make_field(instances, subdivisions, lods=1, with_env=True, prepared=True)
@@ -134,6 +135,56 @@ def secondary_series(W, H, frames, instances, subdivisions):
         r.close()
     torch.cuda.synchronize()
     return out
+
+
+def camera_path_series(W, H, instances, subdivisions, positions=120):
+    """The field seen from a camera that moves: one closed loop of `positions` camera poses (a sideways sway of 30
+    units with a rise and fall of 5, a dolly of 15 units towards the field and a yaw of +-0.25 rad), two-phase occlusion
+    culling on, so every frame's first phase draws what the frame before it saw.  The first loop is the warm-up, the
+    second gives the mean (wall clock over the loop, frames queued back to back like the other series), and a third,
+    on a renderer that brackets every frame's kernels with events and is read back after every frame, the spread over
+    the poses: median, minimum and maximum of a frame's summed kernel time (the brackets add about 0.03 ms to a frame)."""
+    import math
+    from renderer_amd import Renderer, RendererConfig, synth
+    from renderer_amd.scene import Camera
+    scene = synth.make_field(instances, subdivisions, lods=1, with_env=True, prepared=True)
+    norm = math.sqrt(1.0 + 0.35 * 0.35)
+    path = []
+    for k in range(positions):
+        a = 2.0 * math.pi * k / positions
+        yaw = 0.25 * math.sin(a)
+        path.append(Camera((30.0 * math.sin(a), 25.0 + 5.0 * math.sin(2.0 * a), -60.0 + 7.5 * (1.0 - math.cos(a))),
+                           (math.sin(yaw) / norm, 0.35 / norm, -math.cos(yaw) / norm)))
+    r = Renderer(W, H, RendererConfig(lod_enabled=False, cull_enabled=True, collect_stats=True))
+    r.set_scene(scene)
+    for cam in path:
+        r.render(cam)
+    r.sync()
+    t0 = time.perf_counter()
+    for cam in path:
+        r.render(cam)
+    r.sync()
+    mean = (time.perf_counter() - t0) / positions * 1e3
+    st = r.stats()
+    r.close()
+    r = Renderer(W, H, RendererConfig(lod_enabled=False, cull_enabled=True, collect_stats=True, time_kernels=1))
+    r.set_scene(scene)
+    for cam in path[-5:]:
+        r.render(cam)
+    r.stats()
+    per_frame = []
+    for cam in path:
+        r.render(cam)
+        per_frame.append(sum(r.stats()["kernel_ms"].values()))
+    r.close()
+    per_frame.sort()
+    return {"workload": "field, camera on a closed path of %d poses, two-phase occlusion culling on" % positions,
+            "width": W, "height": H, "frames_per_s": 1e3 / mean, "ms_per_frame": mean,
+            "kernel_ms_per_frame_median": per_frame[positions // 2], "kernel_ms_per_frame_min": per_frame[0],
+            "kernel_ms_per_frame_max": per_frame[-1],
+            "Mtri_per_s_submitted": scene.triangle_count() / mean / 1e3,
+            "Mtri_per_s_rasterised": st["triangles_rasterised"] / mean / 1e3,
+            "fragments": st["fragments"], "pixels_covered": st["pixels_covered"]}
 
 
 def spawn_ranks(n):
