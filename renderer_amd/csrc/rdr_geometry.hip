@@ -1321,6 +1321,18 @@ RDR_DEV TileRowWalk tile_row_walk(const SetupTri& t, uint32_t tx0, uint32_t ty) 
     }
     return r;
 }
+// The same for the tiles of one tile column, top to bottom.
+RDR_DEV TileRowWalk tile_col_walk(const SetupTri& t, uint32_t tx, uint32_t ty0) {
+    const int x0 = (int)tx * kTile, y0 = (int)ty0 * kTile;
+    const EdgeEq e[3] = {make_edge(t.X0, t.Y0, t.X1, t.Y1, x0, y0), make_edge(t.X1, t.Y1, t.X2, t.Y2, x0, y0), make_edge(t.X2, t.Y2, t.X0, t.Y0, x0, y0)};
+    TileRowWalk r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        r.v[k] = edge_max(e[k], kTile - 1, kTile - 1) + e[k].bias;
+        r.step[k] = e[k].by * kTile;
+    }
+    return r;
+}
 RDR_DEV bool tile_row_touched(const TileRowWalk& r) { return (r.v[0] | r.v[1] | r.v[2]) >= 0; }
 RDR_DEV void tile_row_next(TileRowWalk& r) {
 #pragma unroll
@@ -1364,6 +1376,16 @@ RDR_DEV void count_tiles(const FrameView& fv, const SetupTri& t, bool valid, uin
         w.masked = __shfl(t.masked, src, 64);
         const uint32_t wx0 = w.px0 / kTile, wy0 = w.py0 / kTile, ww = w.px1 / kTile - wx0 + 1u;
         const uint32_t rows = w.py1 / kTile - wy0 + 1u;
+        if (ww > rows) { // a lane per tile column, walked top to bottom: the shorter way through a box that is wider than high
+            const bool all_rows = !(w.masked & 4u);
+            for (uint32_t col = lane; col < ww; col += 64u) {
+                TileRowWalk r = tile_col_walk(w, wx0 + col, wy0);
+                uint32_t* cnt = &fv.tile_count[wy0 * fv.tiles_x + wx0 + col];
+                for (uint32_t i = 0; i < rows; ++i, tile_row_next(r), cnt += fv.tiles_x)
+                    if (tile_row_touched(r) && (all_rows || tile_row_wanted(fv, w, wy0 + i))) atomicAdd(cnt, 1u);
+            }
+            continue;
+        }
         for (uint32_t row = lane; row < rows; row += 64u) { // a lane per tile row, walked left to right
             const uint32_t ty = wy0 + row;
             if (!tile_row_wanted(fv, w, ty)) continue;
@@ -1375,46 +1397,73 @@ RDR_DEV void count_tiles(const FrameView& fv, const SetupTri& t, bool valid, uin
     }
 }
 
-// The polygon being clipped lives in LDS, a column per lane (vertex- and component-major, so the
-// lanes of a wave hit 64 different banks): Sutherland-Hodgman writes its output at a per-lane index,
-// which in registers means scratch memory, and a chain of dependent scratch accesses was most of this
-// kernel's length (interior scene, 2 400 triangles: 0.028 ms).  A triangle against five planes has at
-// most eight vertices (ten are kept); two buffers, swapped per plane.
+// Set-up works on kSetupChunk triangles per wave at a time, sixteen lanes to a triangle.  The polygon being
+// clipped lives in those lanes' registers, a vertex per lane: against one plane every lane looks at the edge from
+// its vertex to the next (cross-lane reads), keeps its vertex when that is inside and adds the crossing when the
+// edge changes sides, exactly what Sutherland-Hodgman emits for that edge and in the same order, at the index the
+// counts of the lanes before it give (two ballots); the new polygon goes through a small LDS buffer to the lanes
+// that own its vertices.  A plane is one step for all vertices of four triangles instead of a loop over the
+// vertices of each (indexed per lane, which in registers means scratch memory, and in LDS a chain of dependent
+// round trips per vertex: an interior scene's most clipped chunk of sixteen took 9 us to clip and 25 us to fan out,
+// with the kernel waiting for it).  A triangle against five planes has at most eight vertices (ten are kept).
 constexpr int kClipMaxVerts = 10;
+constexpr uint32_t kSetupChunk = 4, kSetupLanes = 16;
+static_assert(kSetupChunk * kSetupLanes == 64 && kClipMaxVerts <= (int)kSetupLanes, "a wave holds kSetupChunk polygons, a vertex per lane");
 struct ClipLds {
-    float v[2][kClipMaxVerts][8][64];
+    float v[8][64]; // [component][triangle of the chunk * kSetupLanes + vertex]
 };
-RDR_DEV ClipVert clip_load(const ClipLds& l, uint32_t lane, int buf, int i) {
+RDR_DEV ClipVert clip_load(const ClipLds& l, uint32_t at) {
+    const float(*v)[64] = l.v;
     ClipVert c;
-    c.x = l.v[buf][i][0][lane]; c.y = l.v[buf][i][1][lane]; c.z = l.v[buf][i][2][lane]; c.w = l.v[buf][i][3][lane];
+    c.x = v[0][at]; c.y = v[1][at]; c.z = v[2][at]; c.w = v[3][at];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) c.uv[k] = l.v[buf][i][4 + k][lane];
+    for (int k = 0; k < 4; ++k) c.uv[k] = v[4 + k][at];
     return c;
 }
-RDR_DEV void clip_store(ClipLds& l, uint32_t lane, int buf, int i, const ClipVert& c) {
-    l.v[buf][i][0][lane] = c.x; l.v[buf][i][1][lane] = c.y; l.v[buf][i][2][lane] = c.z; l.v[buf][i][3][lane] = c.w;
+RDR_DEV void clip_store(ClipLds& l, uint32_t at, const ClipVert& c) {
+    float(*v)[64] = l.v;
+    v[0][at] = c.x; v[1][at] = c.y; v[2][at] = c.z; v[3][at] = c.w;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) l.v[buf][i][4 + k][lane] = c.uv[k];
+    for (int k = 0; k < 4; ++k) v[4 + k][at] = c.uv[k];
+}
+RDR_DEV ClipVert clip_vert_of_lane(const ClipVert& c, uint32_t src) {
+    ClipVert r;
+    r.x = __shfl(c.x, (int)src, 64); r.y = __shfl(c.y, (int)src, 64); r.z = __shfl(c.z, (int)src, 64); r.w = __shfl(c.w, (int)src, 64);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.uv[k] = __shfl(c.uv[k], (int)src, 64);
+    return r;
+}
+RDR_DEV SnapVert snap_vert_of_lane(const SnapVert& c, uint32_t src) {
+    SnapVert r;
+    r.X = __shfl(c.X, (int)src, 64); r.Y = __shfl(c.Y, (int)src, 64); r.z = __shfl(c.z, (int)src, 64); r.inv_w = __shfl(c.inv_w, (int)src, 64);
+    r.u0 = __shfl(c.u0, (int)src, 64); r.v0 = __shfl(c.v0, (int)src, 64); r.u1 = __shfl(c.u1, (int)src, 64); r.v1 = __shfl(c.v1, (int)src, 64);
+    return r;
 }
 
-constexpr uint32_t kSetupChunk = 16;
-// One wave's share of the set-up: wave `wave_index` of `n_waves`, with an LDS polygon buffer of its own.
-RDR_DEV void tile_setup_role(const SceneView& sv, const FrameView& fv, ClipLds& clip, uint32_t wave_index, uint32_t n_waves) {
-    const uint32_t lane = lane_id();
+// One wave's share of the set-up: wave `wave_index` of `n_waves`, with an LDS polygon buffer of its own.  With
+// kBlockWaves > 1 every wave of the workgroup is in here (wave threadIdx.x / 64 of kBlockWaves) and the workgroup
+// reserves its waves' record slots with one atomic per round (`agg`: 2 * (kBlockWaves + 1) words of LDS): the
+// reservations all go to one counter and return a value, about 11 ns apiece, and a frame's few thousand triangles
+// dealt out one by one put a thousand waves in that queue at the same moment.
+template <uint32_t kBlockWaves>
+RDR_DEV void tile_setup_role(const SceneView& sv, const FrameView& fv, ClipLds& clip, uint32_t* agg, uint32_t wave_index, uint32_t n_waves) {
+    const uint32_t lane = lane_id(), first_lane = lane & ~(kSetupLanes - 1u), j = lane & (kSetupLanes - 1u);
     const uint32_t count = min(fv.counters->deferred_count, fv.deferred_capacity);
     const float half_w = (float)fv.width * 0.5f, half_h = (float)fv.height * 0.5f;
-    // A wave takes kSetupChunk triangles at a time, not 64: a record that covers many tiles is counted into its tiles
-    // by the whole wave (count_tiles), one such record after another, and the triangles that come here are mostly of
-    // that kind (walls, floors), so small chunks spread those walks over many more waves; the clipping in front of
-    // them is short by comparison.
+    // A record that covers many tiles is counted into its tiles by the whole wave (count_tiles), one such record after
+    // another, and the triangles that come here are mostly of that kind (walls, floors) and come in runs (a wall's
+    // triangles follow each other in the list): a wave's triangles are taken n_waves apart, so that a run is dealt out
+    // one triangle to a wave.
     const uint32_t stride = n_waves * kSetupChunk;
     // whole waves iterate together so that slots can be reserved with one atomic per wave
-    for (uint32_t base_i = wave_index * kSetupChunk; base_i < count; base_i += stride) {
-        const uint32_t di = base_i + lane;
-        int n = 0, cur = 0; // vertex count and the buffer that holds the polygon
-        bool cull_front = true, masked = false, alpha_draw = false, unclipped = false;
+    uint32_t round = 0;
+    for (uint32_t base_i = 0; base_i < count; base_i += stride, ++round) {
+        const uint32_t di = base_i + (lane / kSetupLanes) * n_waves + wave_index;
+        uint32_t n = 0; // vertices of this lane's polygon; lane j holds vertex j
+        bool cull_front = true, masked = false, alpha_draw = false;
         uint32_t id = 0, draw_id = 0, replicated = 0;
-        if (lane < kSetupChunk && di < count) {
+        ClipVert v{};
+        if (di < count) {
             const DeferredTriangle* dt = &fv.deferred[di];
             draw_id = dt->draw_id;
             id = dt->id;
@@ -1425,101 +1474,113 @@ RDR_DEV void tile_setup_role(const SceneView& sv, const FrameView& fv, ClipLds& 
             const AlphaTest at = make_alpha_test(sv, d);
             masked = at.enabled && at.has_tex;
             n = 3;
-            bool needs = false;
-            for (int k = 0; k < 3; ++k) {
-                ClipVert c;
-                c.x = dt->pos[k][0]; c.y = dt->pos[k][1]; c.z = dt->pos[k][2]; c.w = dt->pos[k][3];
-                for (int j = 0; j < 4; ++j) c.uv[j] = dt->uv[k][j];
-                needs = needs || vert_needs_clip(c.x, c.y, c.z, c.w);
-                clip_store(clip, lane, 0, k, c);
+            if (j < 3u) {
+                v.x = dt->pos[j][0]; v.y = dt->pos[j][1]; v.z = dt->pos[j][2]; v.w = dt->pos[j][3];
+                for (int k = 0; k < 4; ++k) v.uv[k] = dt->uv[j][k];
             }
-            unclipped = !needs;
-            if (needs) {
-                // Sutherland-Hodgman against near + the four guard-band planes
-                for (int plane = 0; plane < 5 && n > 0; ++plane) {
-                    int mcount = 0;
-                    ClipVert p = clip_load(clip, lane, cur, 0);
-                    float dp = plane_dist(p, plane);
-                    for (int i = 0; i < n; ++i) {
-                        const ClipVert q = clip_load(clip, lane, cur, i + 1 < n ? i + 1 : 0);
-                        const float dq = plane_dist(q, plane);
-                        const bool pin = dp >= 0.0f, qin = dq >= 0.0f;
-                        if (pin && mcount < kClipMaxVerts) clip_store(clip, lane, cur ^ 1, mcount++, p);
-                        if (pin != qin && mcount < kClipMaxVerts)
-                            clip_store(clip, lane, cur ^ 1, mcount++, pin ? clip_lerp(p, q, dp, dq) : clip_lerp(q, p, dq, dp));
-                        p = q;
-                        dp = dq;
-                    }
-                    cur ^= 1;
-                    n = mcount;
+        }
+        const unsigned long long needing = __ballot(j < n && vert_needs_clip(v.x, v.y, v.z, v.w));
+        const bool needs = ((needing >> first_lane) & 0xFFFFull) != 0ull, unclipped = !needs;
+        if (needing) {
+            // Sutherland-Hodgman against near + the four guard-band planes
+            for (int plane = 0; plane < 5; ++plane) {
+                const bool active = needs && j < n;
+                const uint32_t next = first_lane | (j + 1u < n ? j + 1u : 0u);
+                const ClipVert q = clip_vert_of_lane(v, next);
+                const float dp = plane_dist(v, plane), dq = __shfl(dp, (int)next, 64);
+                const bool pin = dp >= 0.0f, qin = dq >= 0.0f;
+                const bool keep = active && pin, cross = active && pin != qin;
+                const uint32_t keep_bits = (uint32_t)(__ballot(keep) >> first_lane) & 0xFFFFu, cross_bits = (uint32_t)(__ballot(cross) >> first_lane) & 0xFFFFu;
+                const uint32_t before = (1u << j) - 1u;
+                const uint32_t at = (uint32_t)__popc(keep_bits & before) + (uint32_t)__popc(cross_bits & before);
+                if (keep && at < (uint32_t)kClipMaxVerts) clip_store(clip, first_lane + at, v);
+                if (cross && at + (keep ? 1u : 0u) < (uint32_t)kClipMaxVerts)
+                    clip_store(clip, first_lane + at + (keep ? 1u : 0u), pin ? clip_lerp(v, q, dp, dq) : clip_lerp(q, v, dq, dp));
+                // a wave's LDS instructions execute in the order they were issued: the lanes' stores, then the loads, then
+                // the next plane's stores need no wait between them, only to stay in this order
+                asm volatile("" ::: "memory");
+                if (needs) {
+                    n = min((uint32_t)__popc(keep_bits) + (uint32_t)__popc(cross_bits), (uint32_t)kClipMaxVerts);
+                    if (j < n) v = clip_load(clip, lane);
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+        // fan triangle (0, j + 1, j + 2) in lane j
+        SnapVert own{};
+        if (j < n) own = snap_clip_vert(v, half_w, half_h);
+        const SnapVert s0 = snap_vert_of_lane(own, first_lane), sp = snap_vert_of_lane(own, (lane + 1u) & 63u), sn = snap_vert_of_lane(own, (lane + 2u) & 63u);
+        SetupTri t;
+        SetupMask mk;
+        bool ok = j + 2u < n && make_setup(fv, s0, sp, sn, cull_front, t, mk);
+        t.id = id; t.draw_id = draw_id; t.masked = (masked ? 1u : 0u) | (alpha_draw ? 2u : 0u) | (replicated ? 4u : 0u);
+        // Alpha-tested triangles that k_raster<true> could not enumerate in a lane but that fit a wave
+        // (unclipped, small extent, box within the mid limit) are handed on to k_mid_raster, which runs
+        // after this kernel: same record, same queue as the opaque ones k_raster<false> queues itself.
+        bool to_mid = false;
+        if (ok && alpha_draw && unclipped) {
+            const int32_t ex = max(t.X0, max(t.X1, t.X2)) - min(t.X0, min(t.X1, t.X2));
+            const int32_t ey = max(t.Y0, max(t.Y1, t.Y2)) - min(t.Y0, min(t.Y1, t.Y2));
+            const uint32_t npx = ((uint32_t)t.px1 - t.px0 + 1u) * ((uint32_t)t.py1 - t.py0 + 1u);
+            to_mid = ex <= kSmallExtent && ey <= kSmallExtent && npx <= fv.mid_max_pixels;
+        }
+        const unsigned long long mm = __ballot(to_mid);
+        if (mm) {
+            const int mid_leader = __ffsll((long long)mm) - 1;
+            const uint32_t seg = wave_index % kMidSegments, seg_capacity = fv.mid_capacity / kMidSegments;
+            uint32_t base = 0;
+            if ((int)lane == mid_leader) base = atomicAdd(&fv.counters->mid_seg[seg * 32u], (uint32_t)__popcll(mm));
+            base = __shfl(base, mid_leader, 64);
+            if (to_mid) {
+                const uint32_t in_seg = base + ballot_rank(mm);
+                if (in_seg < seg_capacity) {
+                    fv.mid[seg * seg_capacity + in_seg] = t;
+                    if (masked) fv.mid_mask[seg * seg_capacity + in_seg] = mk;
+                } else {
+                    atomicAdd(&fv.counters->mid_overflow, 1u);
                 }
             }
         }
-        const int max_n = (int)__reduce_max_sync(~0ull, n);
-        SnapVert s0{}, sp{};
-        if (n >= 3) {
-            s0 = snap_clip_vert(clip_load(clip, lane, cur, 0), half_w, half_h);
-            sp = snap_clip_vert(clip_load(clip, lane, cur, 1), half_w, half_h);
-        }
-        for (int i = 2; i < max_n; ++i) { // fan triangle (0, i-1, i), the same i in every lane
-            SetupTri t;
-            SetupMask mk;
-            bool ok = false;
-            if (i < n) {
-                const SnapVert sn = snap_clip_vert(clip_load(clip, lane, cur, i), half_w, half_h);
-                ok = make_setup(fv, s0, sp, sn, cull_front, t, mk);
-                sp = sn;
-            }
-            t.id = id; t.draw_id = draw_id; t.masked = (masked ? 1u : 0u) | (alpha_draw ? 2u : 0u) | (replicated ? 4u : 0u);
-            // Alpha-tested triangles that k_raster<true> could not enumerate in a lane but that fit a wave
-            // (unclipped, small extent, box within the mid limit) are handed on to k_mid_raster, which runs
-            // after this kernel: same record, same queue as the opaque ones k_raster<false> queues itself.
-            bool to_mid = false;
-            if (ok && alpha_draw && unclipped) {
-                const int32_t ex = max(t.X0, max(t.X1, t.X2)) - min(t.X0, min(t.X1, t.X2));
-                const int32_t ey = max(t.Y0, max(t.Y1, t.Y2)) - min(t.Y0, min(t.Y1, t.Y2));
-                const uint32_t npx = ((uint32_t)t.px1 - t.px0 + 1u) * ((uint32_t)t.py1 - t.py0 + 1u);
-                to_mid = ex <= kSmallExtent && ey <= kSmallExtent && npx <= fv.mid_max_pixels;
-            }
-            const unsigned long long mm = __ballot(to_mid);
-            if (mm) {
-                const int mid_leader = __ffsll((long long)mm) - 1;
-                const uint32_t seg = wave_index % kMidSegments, seg_capacity = fv.mid_capacity / kMidSegments;
-                uint32_t base = 0;
-                if ((int)lane == mid_leader) base = atomicAdd(&fv.counters->mid_seg[seg * 32u], (uint32_t)__popcll(mm));
-                base = __shfl(base, mid_leader, 64);
-                if (to_mid) {
-                    const uint32_t in_seg = base + ballot_rank(mm);
-                    if (in_seg < seg_capacity) {
-                        fv.mid[seg * seg_capacity + in_seg] = t;
-                        if (masked) fv.mid_mask[seg * seg_capacity + in_seg] = mk;
-                    } else {
-                        atomicAdd(&fv.counters->mid_overflow, 1u);
-                    }
-                }
-            }
-            ok = ok && !to_mid;
-            const unsigned long long m = __ballot(ok);
+        ok = ok && !to_mid;
+        const unsigned long long m = __ballot(ok);
+        uint32_t slot0 = 0;
+        if (kBlockWaves == 1u) {
             if (!m) continue;
             const int leader = __ffsll((long long)m) - 1;
-            uint32_t slot0 = 0;
             if ((int)lane == leader) slot0 = atomicAdd(&fv.counters->setup_count, (uint32_t)__popcll(m));
             slot0 = __shfl(slot0, leader, 64);
-            const uint32_t slot = slot0 + ballot_rank(m);
-            const bool stored = ok && slot < fv.setup_capacity;
-            if (ok && !stored) atomicAdd(&fv.counters->setup_overflow, 1u);
-            if (stored) {
-                fv.setup[slot] = t;
-                if (masked) fv.setup_mask[slot] = mk;
+        } else {
+            // the rounds alternate between two sets of words: a wave may be a round ahead of one that still reads
+            uint32_t* const a = agg + (round & 1u) * (kBlockWaves + 1u);
+            const uint32_t wave = threadIdx.x >> 6;
+            if (lane == 0u) a[wave] = (uint32_t)__popcll(m);
+            __syncthreads();
+            if (threadIdx.x == 0u) {
+                uint32_t total = 0;
+                for (uint32_t w = 0; w < kBlockWaves; ++w) total += a[w];
+                a[kBlockWaves] = total ? atomicAdd(&fv.counters->setup_count, total) : 0u;
             }
-            count_tiles(fv, t, stored, lane); // the whole wave: wide records are walked by all lanes
+            __syncthreads();
+            slot0 = a[kBlockWaves];
+            for (uint32_t w = 0; w < kBlockWaves; ++w) slot0 += w < wave ? a[w] : 0u;
         }
+        const uint32_t slot = slot0 + ballot_rank(m);
+        const bool stored = ok && slot < fv.setup_capacity;
+        if (ok && !stored) atomicAdd(&fv.counters->setup_overflow, 1u);
+        if (stored) {
+            fv.setup[slot] = t;
+            if (masked) fv.setup_mask[slot] = mk;
+        }
+        count_tiles(fv, t, stored, lane); // the whole wave: wide records are walked by all lanes
     }
 }
 
-__global__ __launch_bounds__(64) void k_tile_setup(SceneView sv, FrameView fv) {
-    __shared__ ClipLds clip;
-    tile_setup_role(sv, fv, clip, blockIdx.x, gridDim.x);
+constexpr uint32_t kSetupWaves = 4;
+__global__ __launch_bounds__(64 * kSetupWaves) void k_tile_setup(SceneView sv, FrameView fv) {
+    __shared__ ClipLds clip[kSetupWaves];
+    __shared__ uint32_t agg[2 * (kSetupWaves + 1)];
+    const uint32_t wave = threadIdx.x >> 6;
+    tile_setup_role<kSetupWaves>(sv, fv, clip[wave], agg, blockIdx.x * kSetupWaves + wave, gridDim.x * kSetupWaves);
 }
 
 // Bin offsets and the bins.  Every workgroup first repeats the prefix sum over the per-tile counts for itself
@@ -1927,7 +1988,7 @@ __global__ __launch_bounds__(256) void k_tile_path_rare(SceneView sv, FrameView 
         return;
     }
     uint32_t round = 0;
-    if (threadIdx.x < 64) tile_setup_role(sv, fv, clip, blockIdx.x, gridDim.x);
+    if (threadIdx.x < 64) tile_setup_role<1>(sv, fv, clip, nullptr, blockIdx.x, gridDim.x);
     bool ok = rare_grid_barrier(fv, gridDim.x, round);
     const uint32_t fill_blocks = gridDim.x / 2u;
     if (ok) {
@@ -2131,7 +2192,7 @@ int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t st
             hipLaunchKernelGGL(k_tile_path_rare, dim3(f.grid.rare_blocks), dim3(256), rdr_tile_fill_lds(n_tiles), stream, sv, f);
             return;
         }
-        hipLaunchKernelGGL(k_tile_setup, dim3(1024), dim3(64), 0, stream, sv, f); // also feeds k_mid_raster
+        hipLaunchKernelGGL(k_tile_setup, dim3(1024 / kSetupWaves), dim3(64 * kSetupWaves), 0, stream, sv, f); // also feeds k_mid_raster
         hipLaunchKernelGGL(k_mid_fill, dim3(f.grid.mid_blocks + kFillBlocks), dim3(256), rdr_tile_fill_lds(n_tiles), stream, sv, f);
         if (mid_event) (void)hipEventRecord(*mid_event, stream);
         hipLaunchKernelGGL(k_tile_raster<kTileBlock>, dim3(f.grid.deferred_blocks), dim3((kTilePart / kTileBlock) * (kTilePart / kTileBlock)), 0, stream, sv, f);
