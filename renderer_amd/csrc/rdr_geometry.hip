@@ -1645,8 +1645,9 @@ RDR_DEV void tile_fill_role(const FrameView& fv, uint32_t block, uint32_t n_bloc
     // the whole wave one after another, and a frame usually has few records but some very wide ones
     // (walls, floors), so small chunks spread those over many more waves.
     const uint32_t wave = (block * blockDim.x + threadIdx.x) >> 6, n_waves = (n_blocks * blockDim.x) >> 6;
-    for (uint32_t base_i = wave * kBinChunk; base_i < count; base_i += n_waves * kBinChunk) {
-        const uint32_t i = base_i + lane;
+    // (a wave's records are taken n_waves apart: wide records come in runs, and a run is dealt out one record to a wave)
+    for (uint32_t base_i = 0; base_i < count; base_i += n_waves * kBinChunk) {
+        const uint32_t i = base_i + lane * n_waves + wave;
         uint32_t tx0 = 0, ty0 = 0, tw = 1, nt = 0;
         SetupTri t;
         if (lane < kBinChunk && i < count) {
@@ -1667,7 +1668,7 @@ RDR_DEV void tile_fill_role(const FrameView& fv, uint32_t block, uint32_t n_bloc
         while (wide) {
             const int src = __ffsll((long long)wide) - 1;
             wide &= wide - 1ull;
-            const uint32_t record = base_i + (uint32_t)src;
+            const uint32_t record = base_i + (uint32_t)src * n_waves + wave;
             const SetupTri w = fv.setup[record]; // the same address in every lane: one broadcast load
             const uint32_t wx0 = w.px0 / kTile, wy0 = w.py0 / kTile, ww = w.px1 / kTile - wx0 + 1u;
             const uint32_t rows = w.py1 / kTile - wy0 + 1u;
