@@ -1758,8 +1758,13 @@ RDR_DEV void tile_raster_role(const SceneView& sv, const FrameView& fv, uint32_t
     __shared__ SetupTri batch[kTileBatch];
     __shared__ uint32_t batch_index[kTileBatch];
     __shared__ uint32_t wg_frags[kWaves];
+    // The three edge functions of a staged record at the centre of the job's first pixel, in double precision (exact:
+    // below 2^50 inside the guard band): value, change per pixel in x and in y, and the value the function has to
+    // reach at a pixel for the pixel to be inside (0 on top-left edges, 1 on the others).
+    __shared__ double edge_lds[kTileJob][3][4];
     static_assert(kTileJob <= kTileBatch, "a job is staged in one batch");
     uint32_t frags = 0;
+    const double block_x = (double)((threadIdx.x % kSide) * B), block_y = (double)((threadIdx.x / kSide) * B); // this thread's block in the piece
     const uint32_t n_listed = min(fv.counters->tile_nonempty, fv.tile_list_capacity);
     // Jobs are dealt out by index, a grid's width apart: a shared counter would cost an atomic that returns a
     // value per job, and those serialise on their address (10 000 jobs: 0.1 ms).
@@ -1796,8 +1801,19 @@ RDR_DEV void tile_raster_role(const SceneView& sv, const FrameView& fv, uint32_t
                 const uint32_t r = threadIdx.x >> 2, part = threadIdx.x & 3u;
                 if (r < nb) {
                     const uint32_t idx = fv.bin_entries[off + b0 + r];
-                    reinterpret_cast<uint4*>(&batch[r])[part] = reinterpret_cast<const uint4*>(&fv.setup[idx])[part];
+                    const SetupTri* src = &fv.setup[idx];
+                    reinterpret_cast<uint4*>(&batch[r])[part] = reinterpret_cast<const uint4*>(src)[part];
                     if (part == 0) batch_index[r] = idx;
+                    if (part < 3u) { // three of the four set up an edge each: 0 from vertex 0 to 1 (the weight of vertex 2), 1 from 1 to 2, 2 from 2 to 0
+                        const int32_t* xy = &src->X0;
+                        const uint32_t a = part, b = part == 2u ? 0u : part + 1u;
+                        const int32_t Xa = xy[2u * a], Ya = xy[2u * a + 1u], dx = xy[2u * b] - Xa, dy = xy[2u * b + 1u] - Ya;
+                        double* e = edge_lds[r][part];
+                        e[0] = (double)dx * (double)(tile_y0 * 256 + 128 - Ya) - (double)dy * (double)(tile_x0 * 256 + 128 - Xa);
+                        e[1] = -(double)dy * 256.0;
+                        e[2] = (double)dx * 256.0;
+                        e[3] = (dy < 0 || (dy == 0 && dx > 0)) ? 0.0 : 1.0;
+                    }
                 }
             }
             __syncthreads();
@@ -1806,23 +1822,26 @@ RDR_DEV void tile_raster_role(const SceneView& sv, const FrameView& fv, uint32_t
                 const SetupTri& t = batch[k];
                 if ((int)t.px1 < bx0 || (int)t.px0 > bx0 + (B - 1) || (int)t.py1 < by0 || (int)t.py0 > by0 + (B - 1)) continue;
                 if ((t.masked & 4u) && !rows_mine) continue;
-                const EdgeEq e01 = make_edge(t.X0, t.Y0, t.X1, t.Y1, bx0, by0); // weight of v2
-                const EdgeEq e12 = make_edge(t.X1, t.Y1, t.X2, t.Y2, bx0, by0); // weight of v0
-                const EdgeEq e20 = make_edge(t.X2, t.Y2, t.X0, t.Y0, bx0, by0); // weight of v1
-                if (edge_max(e01, B - 1, B - 1) + e01.bias < 0 || edge_max(e12, B - 1, B - 1) + e12.bias < 0 || edge_max(e20, B - 1, B - 1) + e20.bias < 0) continue;
                 const float z0 = t.z0, dz1 = t.dz1, dz2 = t.dz2, inv_area = t.inv_area;
                 const uint32_t id = t.id;
                 if (!(t.masked & 2u)) {
-                    // opaque: branch-free over the block's pixels; the depth is evaluated everywhere and kept where covered
+                    // opaque: branch-free over the block's pixels; the depth is evaluated everywhere and kept where covered.
+                    // The edge functions run in double precision from the staged set-up: the same integers as the 64-bit
+                    // form, exactly, with one instruction per addition and per conversion to float.
+                    const double* ea = edge_lds[k][0];
+                    const double* eb = edge_lds[k][1];
+                    const double* ec = edge_lds[k][2];
+                    const double a0 = fma(ea[1], block_x, fma(ea[2], block_y, ea[0])), b0 = fma(eb[1], block_x, fma(eb[2], block_y, eb[0])),
+                                 c0 = fma(ec[1], block_x, fma(ec[2], block_y, ec[0]));
 #pragma unroll
                     for (int j = 0; j < B; ++j) {
 #pragma unroll
                         for (int i = 0; i < B; ++i) {
-                            const long long v01 = e01.e + e01.ax * i + e01.by * j;
-                            const long long v12 = e12.e + e12.ax * i + e12.by * j;
-                            const long long v20 = e20.e + e20.ax * i + e20.by * j;
-                            const bool in = (((v01 + e01.bias) | (v12 + e12.bias) | (v20 + e20.bias)) >= 0) & ((on_screen >> (j * B + i)) & 1u);
-                            const float l1 = edge_to_float(v20) * inv_area, l2 = edge_to_float(v01) * inv_area;
+                            const double v01 = a0 + (ea[1] * (double)i + ea[2] * (double)j);
+                            const double v12 = b0 + (eb[1] * (double)i + eb[2] * (double)j);
+                            const double v20 = c0 + (ec[1] * (double)i + ec[2] * (double)j);
+                            const bool in = (v01 >= ea[3]) & (v12 >= eb[3]) & (v20 >= ec[3]) & (bool)((on_screen >> (j * B + i)) & 1u);
+                            const float l1 = (float)v20 * inv_area, l2 = (float)v01 * inv_area;
                             const float z = clampf(fmaf(l2, dz2, fmaf(l1, dz1, z0)), 0.0f, 1.0f);
                             const unsigned long long key = ((unsigned long long)(0x7FFFFFFFu - __float_as_uint(z)) << 32) | (unsigned long long)id;
                             keys[j * B + i] = (in && key < keys[j * B + i]) ? key : keys[j * B + i];
@@ -1831,6 +1850,10 @@ RDR_DEV void tile_raster_role(const SceneView& sv, const FrameView& fv, uint32_t
                     }
                     continue;
                 }
+                const EdgeEq e01 = make_edge(t.X0, t.Y0, t.X1, t.Y1, bx0, by0); // weight of v2
+                const EdgeEq e12 = make_edge(t.X1, t.Y1, t.X2, t.Y2, bx0, by0); // weight of v0
+                const EdgeEq e20 = make_edge(t.X2, t.Y2, t.X0, t.Y0, bx0, by0); // weight of v1
+                if (edge_max(e01, B - 1, B - 1) + e01.bias < 0 || edge_max(e12, B - 1, B - 1) + e12.bias < 0 || edge_max(e20, B - 1, B - 1) + e20.bias < 0) continue;
                 const AlphaTest at = make_alpha_test(sv, uniform_ref(&sv.draws[__builtin_amdgcn_readfirstlane(t.draw_id)])); // one record for all threads
                 const SetupMask* mk = (t.masked & 1u) ? &fv.setup_mask[batch_index[k]] : nullptr;
                 // alpha-tested: coverage of the block first, then the texture is consulted only where it matters
