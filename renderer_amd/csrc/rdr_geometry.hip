@@ -27,6 +27,7 @@ constexpr float kGuardBand = 8.0f;
 constexpr int kSmallExtent = 64 * 256; // bounding boxes up to 64 px on a side stay in k_raster / k_mid_raster (int32 exact); see FrameView::lane_max_pixels
 constexpr int kTile = 64;              // screen tile of the binned path, pixels
 constexpr int kTileBatch = 64;
+constexpr uint32_t kJobGroup = 4;      // k_tile_raster: jobs a workgroup fetches together
 constexpr int kTilePart = 32;           // k_tile_raster: a job covers a kTilePart x kTilePart piece of a tile
 constexpr uint32_t kTileParts = (kTile / kTilePart) * (kTile / kTilePart);
 static_assert(kTileParts <= kTileJob, "the part index travels in the low bits of the job's first record");
@@ -1761,23 +1762,58 @@ RDR_DEV void tile_raster_role(const SceneView& sv, const FrameView& fv, uint32_t
     // The three edge functions of a staged record at the centre of the job's first pixel, in double precision (exact:
     // below 2^50 inside the guard band): value, change per pixel in x and in y, and the value the function has to
     // reach at a pixel for the pixel to be inside (0 on top-left edges, 1 on the others).
-    __shared__ double edge_lds[kTileJob][3][4];
-    static_assert(kTileJob <= kTileBatch, "a job is staged in one batch");
+    __shared__ double edge_lds[kJobGroup * kTileJob][3][4];
+    __shared__ uint4 job_lds[kJobGroup]; // tile, first record | part, first bin entry, records | bit 31: other jobs work on the same pixels
+    static_assert(kJobGroup * kTileJob <= kTileBatch && kSide * kSide == 64 * (int)kJobGroup, "a group of jobs is staged at once, 64 threads to a job");
     uint32_t frags = 0;
     const double block_x = (double)((threadIdx.x % kSide) * B), block_y = (double)((threadIdx.x / kSide) * B); // this thread's block in the piece
     const uint32_t n_listed = min(fv.counters->tile_nonempty, fv.tile_list_capacity);
     // Jobs are dealt out by index, a grid's width apart: a shared counter would cost an atomic that returns a
-    // value per job, and those serialise on their address (10 000 jobs: 0.1 ms).
-    for (uint32_t this_li = block; this_li < n_listed; this_li += n_blocks) {
-        const uint2 job = fv.tile_list[this_li];
-        const uint32_t tile = job.x;
-        const uint32_t n_all = fv.tile_count[tile];
-        const uint32_t tile_off = fv.tile_offset[tile];
-        const uint32_t n_tile = tile_off >= fv.bin_capacity ? 0u : min(n_all, fv.bin_capacity - tile_off); // records that made it into the bin
-        const uint32_t first = job.y & ~(kTileJob - 1u), part = job.y & (kTileJob - 1u);
-        const uint32_t off = tile_off + first;
-        const uint32_t n = first < n_tile ? min(kTileJob, n_tile - first) : 0u;
-        const bool shared_tile = n_all > kTileJob; // other jobs work on the same pixels: merge with atomics
+    // value per job, and those serialise on their address (10 000 jobs: 0.1 ms).  A workgroup fetches kJobGroup of
+    // its jobs at a time: what a job costs is mostly the chain of dependent loads in front of its arithmetic (list
+    // -> count, offset -> bin -> records), and the jobs of a group walk that chain side by side.
+    for (uint32_t li0 = block; li0 < n_listed; li0 += n_blocks * kJobGroup) {
+        __syncthreads(); // the previous group has been consumed
+        if (threadIdx.x < kJobGroup) {
+            const uint32_t li = li0 + threadIdx.x * n_blocks;
+            uint4 j = make_uint4(0u, 0u, 0u, 0u);
+            if (li < n_listed) {
+                const uint2 job = fv.tile_list[li];
+                const uint32_t n_all = fv.tile_count[job.x], tile_off = fv.tile_offset[job.x];
+                const uint32_t n_tile = tile_off >= fv.bin_capacity ? 0u : min(n_all, fv.bin_capacity - tile_off); // records that made it into the bin
+                const uint32_t first = job.y & ~(kTileJob - 1u);
+                j = make_uint4(job.x, job.y, tile_off + first, (first < n_tile ? min(kTileJob, n_tile - first) : 0u) | (n_all > kTileJob ? 0x80000000u : 0u));
+            }
+            job_lds[threadIdx.x] = j;
+        }
+        __syncthreads();
+        {   // stage the group's records: 64 threads per job, 4 per 64-byte record (coalesced 16-byte loads)
+            const uint32_t jk = threadIdx.x >> 6, r = (threadIdx.x & 63u) >> 2, part = threadIdx.x & 3u;
+            const uint4 j = job_lds[jk];
+            if (r < (j.w & 0x7FFFFFFFu)) {
+                const uint32_t idx = fv.bin_entries[j.z + r], piece = j.y & (kTileJob - 1u);
+                const int piece_x0 = (int)(j.x % fv.tiles_x) * kTile + (int)(piece % (kTile / kTilePart)) * kTilePart;
+                const int piece_y0 = (int)(j.x / fv.tiles_x) * kTile + (int)(piece / (kTile / kTilePart)) * kTilePart;
+                const SetupTri* src = &fv.setup[idx];
+                reinterpret_cast<uint4*>(&batch[jk * kTileJob + r])[part] = reinterpret_cast<const uint4*>(src)[part];
+                if (part == 0) batch_index[jk * kTileJob + r] = idx;
+                if (part < 3u) { // three of the four set up an edge each: 0 from vertex 0 to 1 (the weight of vertex 2), 1 from 1 to 2, 2 from 2 to 0
+                    const int32_t* xy = &src->X0;
+                    const uint32_t a = part, b = part == 2u ? 0u : part + 1u;
+                    const int32_t Xa = xy[2u * a], Ya = xy[2u * a + 1u], dx = xy[2u * b] - Xa, dy = xy[2u * b + 1u] - Ya;
+                    double* e = edge_lds[jk * kTileJob + r][part];
+                    e[0] = (double)dx * (double)(piece_y0 * 256 + 128 - Ya) - (double)dy * (double)(piece_x0 * 256 + 128 - Xa);
+                    e[1] = -(double)dy * 256.0;
+                    e[2] = (double)dx * 256.0;
+                    e[3] = (dy < 0 || (dy == 0 && dx > 0)) ? 0.0 : 1.0;
+                }
+            }
+        }
+        __syncthreads();
+    for (uint32_t jk = 0; jk < kJobGroup; ++jk) {
+        const uint4 this_job = job_lds[jk];
+        const uint32_t tile = this_job.x, part = this_job.y & (kTileJob - 1u), n = this_job.w & 0x7FFFFFFFu, rec0 = jk * kTileJob;
+        const bool shared_tile = (this_job.w >> 31) != 0u; // other jobs work on the same pixels: merge with atomics
         if (n == 0u) continue;
         // the job's part of the tile, and this thread's B x B pixel block in it
         const int tile_x0 = (int)(tile % fv.tiles_x) * kTile + (int)(part % (kTile / kTilePart)) * kTilePart;
@@ -1794,32 +1830,9 @@ RDR_DEV void tile_raster_role(const SceneView& sv, const FrameView& fv, uint32_t
             on_screen |= (bx0 + (k % B) < (int)fv.width && by0 + (k / B) < (int)fv.height) ? (1u << k) : 0u;
         }
 
-        for (uint32_t b0 = 0; b0 < n; b0 += kTileBatch) {
-            const uint32_t nb = min((uint32_t)kTileBatch, n - b0);
-            __syncthreads(); // the previous batch has been consumed
-            {   // stage the batch: 4 threads per 64-byte record, coalesced 16-byte loads
-                const uint32_t r = threadIdx.x >> 2, part = threadIdx.x & 3u;
-                if (r < nb) {
-                    const uint32_t idx = fv.bin_entries[off + b0 + r];
-                    const SetupTri* src = &fv.setup[idx];
-                    reinterpret_cast<uint4*>(&batch[r])[part] = reinterpret_cast<const uint4*>(src)[part];
-                    if (part == 0) batch_index[r] = idx;
-                    if (part < 3u) { // three of the four set up an edge each: 0 from vertex 0 to 1 (the weight of vertex 2), 1 from 1 to 2, 2 from 2 to 0
-                        const int32_t* xy = &src->X0;
-                        const uint32_t a = part, b = part == 2u ? 0u : part + 1u;
-                        const int32_t Xa = xy[2u * a], Ya = xy[2u * a + 1u], dx = xy[2u * b] - Xa, dy = xy[2u * b + 1u] - Ya;
-                        double* e = edge_lds[r][part];
-                        e[0] = (double)dx * (double)(tile_y0 * 256 + 128 - Ya) - (double)dy * (double)(tile_x0 * 256 + 128 - Xa);
-                        e[1] = -(double)dy * 256.0;
-                        e[2] = (double)dx * 256.0;
-                        e[3] = (dy < 0 || (dy == 0 && dx > 0)) ? 0.0 : 1.0;
-                    }
-                }
-            }
-            __syncthreads();
-            if (!block_on_screen) continue;
-            for (uint32_t k = 0; k < nb; ++k) {
-                const SetupTri& t = batch[k];
+        if (block_on_screen) {
+            for (uint32_t k = 0; k < n; ++k) {
+                const SetupTri& t = batch[rec0 + k];
                 if ((int)t.px1 < bx0 || (int)t.px0 > bx0 + (B - 1) || (int)t.py1 < by0 || (int)t.py0 > by0 + (B - 1)) continue;
                 if ((t.masked & 4u) && !rows_mine) continue;
                 const float z0 = t.z0, dz1 = t.dz1, dz2 = t.dz2, inv_area = t.inv_area;
@@ -1828,18 +1841,20 @@ RDR_DEV void tile_raster_role(const SceneView& sv, const FrameView& fv, uint32_t
                     // opaque: branch-free over the block's pixels; the depth is evaluated everywhere and kept where covered.
                     // The edge functions run in double precision from the staged set-up: the same integers as the 64-bit
                     // form, exactly, with one instruction per addition and per conversion to float.
-                    const double* ea = edge_lds[k][0];
-                    const double* eb = edge_lds[k][1];
-                    const double* ec = edge_lds[k][2];
+                    const double* ea = edge_lds[rec0 + k][0];
+                    const double* eb = edge_lds[rec0 + k][1];
+                    const double* ec = edge_lds[rec0 + k][2];
                     const double a0 = fma(ea[1], block_x, fma(ea[2], block_y, ea[0])), b0 = fma(eb[1], block_x, fma(eb[2], block_y, eb[0])),
                                  c0 = fma(ec[1], block_x, fma(ec[2], block_y, ec[0]));
 #pragma unroll
                     for (int j = 0; j < B; ++j) {
 #pragma unroll
                         for (int i = 0; i < B; ++i) {
-                            const double v01 = a0 + (ea[1] * (double)i + ea[2] * (double)j);
-                            const double v12 = b0 + (eb[1] * (double)i + eb[2] * (double)j);
-                            const double v20 = c0 + (ec[1] * (double)i + ec[2] * (double)j);
+                            // (sums of integers below 2^53: exact in any order)
+                            const double v01 = i ? (j ? (a0 + ea[1]) + ea[2] : a0 + ea[1]) : (j ? a0 + ea[2] : a0);
+                            const double v12 = i ? (j ? (b0 + eb[1]) + eb[2] : b0 + eb[1]) : (j ? b0 + eb[2] : b0);
+                            const double v20 = i ? (j ? (c0 + ec[1]) + ec[2] : c0 + ec[1]) : (j ? c0 + ec[2] : c0);
+                            static_assert(B == 2, "the four pixels of a 2 x 2 block");
                             const bool in = (v01 >= ea[3]) & (v12 >= eb[3]) & (v20 >= ec[3]) & (bool)((on_screen >> (j * B + i)) & 1u);
                             const float l1 = (float)v20 * inv_area, l2 = (float)v01 * inv_area;
                             const float z = clampf(fmaf(l2, dz2, fmaf(l1, dz1, z0)), 0.0f, 1.0f);
@@ -1855,7 +1870,7 @@ RDR_DEV void tile_raster_role(const SceneView& sv, const FrameView& fv, uint32_t
                 const EdgeEq e20 = make_edge(t.X2, t.Y2, t.X0, t.Y0, bx0, by0); // weight of v1
                 if (edge_max(e01, B - 1, B - 1) + e01.bias < 0 || edge_max(e12, B - 1, B - 1) + e12.bias < 0 || edge_max(e20, B - 1, B - 1) + e20.bias < 0) continue;
                 const AlphaTest at = make_alpha_test(sv, uniform_ref(&sv.draws[__builtin_amdgcn_readfirstlane(t.draw_id)])); // one record for all threads
-                const SetupMask* mk = (t.masked & 1u) ? &fv.setup_mask[batch_index[k]] : nullptr;
+                const SetupMask* mk = (t.masked & 1u) ? &fv.setup_mask[batch_index[rec0 + k]] : nullptr;
                 // alpha-tested: coverage of the block first, then the texture is consulted only where it matters
                 uint32_t cov = 0;
 #pragma unroll
@@ -1937,6 +1952,7 @@ RDR_DEV void tile_raster_role(const SceneView& sv, const FrameView& fv, uint32_t
             }
             if (any) touch_pixel(fv, bx0, by0); // B divides the tile edge: the block lies in one tile
         }
+    }
     }
     if (fv.collect_stats) {
         const uint32_t f = wave_sum(frags);
