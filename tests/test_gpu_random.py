@@ -11,10 +11,10 @@ from renderer_amd.scene import Camera, Scene, mat4_trs
 pytestmark = pytest.mark.gpu
 
 
-def soup(rng, n_tris, masked):
+def soup(rng, n_tris, masked, size_exponents=(-3.0, 2.0)):
     """Triangles in front of, around and behind a camera at the origin looking along +z (direction
     (0,0,-1): the view looks along -direction)."""
-    sizes = 10.0 ** rng.uniform(-3.0, 2.0, n_tris)              # edge length: 1e-3 .. 100 world units
+    sizes = 10.0 ** rng.uniform(size_exponents[0], size_exponents[1], n_tris)  # edge length: 1e-3 .. 100 world units
     centre = np.stack([rng.uniform(-6, 6, n_tris), rng.uniform(-4, 4, n_tris), rng.uniform(-3, 40, n_tris)], 1)
     tri = centre[:, None, :] + rng.normal(size=(n_tris, 3, 3)) * sizes[:, None, None]
     degenerate = rng.random(n_tris) < 0.03
@@ -65,6 +65,29 @@ def test_triangle_soup(oracle, seed, w, h, masked):
             err = np.abs(g.read_color().astype(np.int32) - ref.astype(np.int32))
             assert err.max() <= 2, f"seed {seed} view {k}: colour error {err.max()}"
         g.close()
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_more_large_triangles_than_one_round_of_the_tile_setup_takes(oracle, masked):
+    """Thousands of large and clipped triangles: the tile path's set-up takes 4 096 triangles per round (four to a wave),
+    so this many go through several rounds of it, and the bins hold hundreds of records per tile."""
+    rng = np.random.default_rng(77)
+    sc = soup(rng, 6000, masked, size_exponents=(0.3, 2.0))
+    w, h = 200, 120
+    o = oracle.OracleRenderer(w, h, RendererConfig(cull_enabled=False))
+    o.set_scene(sc)
+    g = Renderer(w, h, RendererConfig(cull_enabled=False))
+    g.set_scene(sc)
+    for k in range(2):
+        cam = Camera((0.2 * k, 0.0, -0.3 * k), (np.sin(0.3 * k), 0.0, -np.cos(0.3 * k)))
+        ovis = o.render_visbuffer(cam, (0.3, 0.8, -0.4))
+        g.render(cam, (0.3, 0.8, -0.4))
+        assert g.frame_status() == 0
+        st = g.stats()
+        assert st["triangles_big"] > 4096, st["triangles_big"]
+        gvis = g.read_visbuffer_u64()
+        assert np.array_equal(gvis, ovis), f"view {k}: {(gvis != ovis).sum()} keys differ"
+    g.close()
 
 
 def test_empty_scene_and_scene_without_visible_geometry(oracle):
