@@ -151,6 +151,9 @@ RDR_DEV Ray make_ray(vec3 o, vec3 d, float tmax) {
     r.slab.rx = d.x < 0.0f ? 16u : 0u;
     r.slab.ry = d.y < 0.0f ? 16u : 0u;
     r.slab.rz = d.z < 0.0f ? 16u : 0u;
+    // the compiler is not to know that these are 0 or 16: it would turn every rotation by them into a rotation by 16
+    // and a select on the sign, two instructions (one with a scalar-register mask) for one
+    asm volatile("" : "+v"(r.slab.rx), "+v"(r.slab.ry), "+v"(r.slab.rz));
     return r;
 }
 
