@@ -610,10 +610,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 // deep scratch-backed stack, whatever overflowed the LDS stack (in k_shadow or here).  The two kinds are
 // rare and evenly spread over the list, so every workgroup has about the same little to do.
 constexpr uint32_t kWalkChunk = 4096;
+// The LDS a workgroup holds decides how many of them walk on a compute unit at a time (each has one full wave of rays
+// and a second with the rest): sixteen stack rows (the walks through one instance of the scenes measured never hold
+// more than eight entries; more than sixteen go to the deep stack) and 16-bit list entries make it 25 KB, six
+// workgroups per compute unit, where the full 24 rows and 32-bit entries made it 42 KB and three -- an 8K frame's
+// 4 700 workgroups then went through in six rounds.
+constexpr int kWalkStackRows = 16;
+static_assert(kWalkStackRows <= kLdsStack && kWalkChunk <= (1u << 14), "a list entry is the offset in the chunk and a two-bit code in 16 bits");
 
 __global__ __launch_bounds__(256) void k_shadow_walk(SceneView sv, FrameView fv) {
-    __shared__ uint32_t stack_mem[(kLdsStack + 1) * 256];
-    __shared__ uint32_t open_list[kWalkChunk];
+    __shared__ uint32_t stack_mem[(kWalkStackRows + 1) * 256];
+    __shared__ uint16_t open_list[kWalkChunk];
     __shared__ uint32_t open_count;
     const uint32_t count = fv.counters->pixel_count;
     const uint32_t chunk0 = blockIdx.x * kWalkChunk;
@@ -627,20 +634,20 @@ __global__ __launch_bounds__(256) void k_shadow_walk(SceneView sv, FrameView fv)
 #pragma unroll
         for (uint32_t k = 0; k < 16u; ++k) {
             const uint32_t code = (w[k >> 2] >> ((k & 3u) * 8u)) & 0xFFu;
-            if (code >= kShadowRetrace && e0 + k < count) open_list[atomicAdd(&open_count, 1u)] = ((e0 + k) << 2) | code;
+            if (code >= kShadowRetrace && e0 + k < count) open_list[atomicAdd(&open_count, 1u)] = (uint16_t)(((threadIdx.x * 16u + k) << 2) | code);
         }
     }
     __syncthreads();
     const uint32_t n = open_count;
     for (uint32_t i = threadIdx.x; i < n; i += 256u) {
-        const uint32_t entry = open_list[i] >> 2;
+        const uint32_t entry = chunk0 + (open_list[i] >> 2);
         uint32_t code = open_list[i] & 3u;
         const ShadowRay r = shadow_ray_of(sv, fv, entry);
         bool deferred, h = false;
         if (code == kShadowWalkOwn) {
             LdsStack st;
             st.base = stack_mem + threadIdx.x;
-            st.limit = (int)fv.lds_stack_limit;
+            st.limit = min((int)fv.lds_stack_limit, kWalkStackRows);
             h = shadow_any_hit(sv, r.draw_id, r.skip_own, r.o, r.d, kShadowTmin, kShadowTmax, st, kTraceOwn, deferred);
             code = (!h && st.overflow) ? kShadowRetrace + 4u : 0u; // 6: the own instance once more, with the deep stack
         }
