@@ -11,6 +11,9 @@ w, h = 3840, 2160
 if scene_name == "field":  # exactly bench.py's single-GPU workload
     scene = synth.make_field(1250, 5, lods=1, with_env=True, prepared=True)
     conf = RendererConfig(lod_enabled=False, cull_enabled=False, collect_stats=True, time_kernels=True)
+elif scene_name == "occfield":  # the headline field with two-phase occlusion culling on
+    scene = synth.make_field(1250, 5, lods=1, with_env=True, prepared=True)
+    conf = RendererConfig(lod_enabled=False, cull_enabled=True, collect_stats=True, time_kernels=True)
 elif scene_name == "lodfield":  # the field with LOD selection on: coarse levels, mid-size triangles dominate
     scene = synth.make_field(1250, 5, lods=8, with_env=True, prepared=True)
     conf = RendererConfig(lod_enabled=True, cull_enabled=False, collect_stats=True, time_kernels=True)

@@ -1724,7 +1724,7 @@ __global__ __launch_bounds__(256) void k_mid_fill(SceneView sv, FrameView fv) {
 // counts the next frame will use are zeroed (FrameView::counters_next; spread over the grid), and the pass's status
 // goes where the host sees it without a synchronisation.  Every producer of the lists has finished (earlier
 // kernels), so the overflow counters are final; with two-phase culling a frame has two passes and the flags and the
-// tile-path hint accumulate in the frame's counters, which k_phase_reset leaves alone.
+// tile-path hint accumulate in the frame's counters, which the reset between the phases (phase_reset) leaves alone.
 RDR_DEV void pass_epilogue(const FrameView& fv, uint32_t block, uint32_t n_blocks) {
     const uint32_t n_words = (uint32_t)(sizeof(FrameCounters) / 4u), n_tiles = fv.tiles_x * fv.tiles_y;
     for (uint32_t w = block * blockDim.x + threadIdx.x; w < n_words + n_tiles; w += n_blocks * blockDim.x) {
@@ -2047,41 +2047,63 @@ __global__ __launch_bounds__(256) void k_tile_path_rare(SceneView sv, FrameView 
 // bits = 0x7FFFFFFF - (key >> 32), 0 where nothing was drawn.  Positive floats order like
 // their bit patterns, so levels hold raw bits and reduce with an integer min.
 // k_pyramid_tiles: one workgroup per 64x64 pixels writes levels 0..5 of its region (a thread
-// owns 4x4 pixels); k_pyramid_top: one workgroup finishes the remaining levels.
+// reduces 2x2 pixels at a time, four times); k_pyramid_top: one workgroup finishes the remaining levels.
 // ------------------------------------------------------------------------------
+// Between the phases: empty the work lists the early phase filled.  Part of k_pyramid_tiles (which runs between the
+// phases and touches none of this): workgroup b clears tile b's count, the first one the counters.
+RDR_DEV void phase_reset(const FrameView& fv, uint32_t block, uint32_t gi) {
+    if (gi == 0) fv.tile_count[block] = 0u;
+    if (block != 0u) return;
+    if (gi == 0) {
+        FrameCounters* c = fv.counters;
+        c->cmd_count = 0; c->vis_count = 0; c->vis_mask_count = 0; c->deferred_count = 0;
+        c->setup_count = 0; c->bin_total = 0; c->tile_nonempty = 0;
+        c->rare_barrier = 0; // the late pass's k_tile_path_rare counts its own arrivals
+    }
+    if (gi < kMidSegments) fv.counters->mid_seg[gi * 32u] = 0u;
+    if (gi < kFragSegments) fv.counters->frag_seg[gi * 16u] = 0ull;
+    for (uint32_t t = gi; t < 2u * kRasterSegments; t += 256u) fv.counters->raster_ticket[t / kRasterSegments][(t % kRasterSegments) * 32u] = 0u;
+}
 __global__ __launch_bounds__(256) void k_pyramid_tiles(FrameView fv) {
     __shared__ uint32_t lds[256];
+    phase_reset(fv, blockIdx.y * gridDim.x + blockIdx.x, threadIdx.x);
     const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
-    const uint32_t bx0 = blockIdx.x * 64u + tx * 4u, by0 = blockIdx.y * 64u + ty * 4u;
-    uint32_t q[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}; // the block's 2x2 level-0 texels
-    if (bx0 < fv.width && by0 < fv.height) {
+    // Levels 0 and 1: a thread reduces 2x2 pixels (a level-0 texel) at a time, a wave two rows of 64 pixels and the
+    // two below them: consecutive lanes read consecutive 16 bytes (two keys).  The four level-0 texels of a level-1
+    // texel are in lanes l, l ^ 1, l ^ 32 and l ^ 33.
+    const uint32_t cp = threadIdx.x & 31u, rp0 = threadIdx.x >> 5; // pair of columns in the tile, first of this thread's four pairs of rows
+    const uint32_t x0 = blockIdx.x * 64u + cp * 2u;
+    const bool aligned_pairs = (fv.width & 1u) == 0u; // every pair of keys is 16-byte aligned, and on the screen as a whole
 #pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) {
-            if (by0 + j >= fv.height) continue;
-            const unsigned long long* row = fv.vis + (size_t)(by0 + j) * fv.width + bx0;
+    for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t rp = rp0 + 8u * k, y0 = blockIdx.y * 64u + rp * 2u;
+        uint32_t m = 0xFFFFFFFFu; // min of the depths = 0x7FFFFFFF - max of the keys' high words (at most 0x7FFFFFFF, the cleared key's)
 #pragma unroll
-            for (uint32_t i = 0; i < 4; ++i) {
-                if (bx0 + i >= fv.width) continue;
-                const uint32_t d = 0x7FFFFFFFu - (uint32_t)(row[i] >> 32);
-                uint32_t& t = q[(j >> 1) * 2u + (i >> 1)];
-                t = min(t, d);
+        for (uint32_t r = 0; r < 2u; ++r) {
+            if (x0 >= fv.width || y0 + r >= fv.height) continue;
+            const unsigned long long* row = fv.vis + (size_t)(y0 + r) * fv.width + x0;
+            if (aligned_pairs) {
+                const uint4 a = *reinterpret_cast<const uint4*>(row);
+                m = min(m, 0x7FFFFFFFu - max(a.y, a.w));
+            } else {
+                m = min(m, 0x7FFFFFFFu - (uint32_t)(row[0] >> 32));
+                if (x0 + 1u < fv.width) m = min(m, 0x7FFFFFFFu - (uint32_t)(row[1] >> 32));
             }
         }
-        // level 0: 2x2 texels per thread
-#pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) {
-            const uint32_t x = (bx0 >> 1) + (k & 1u), y = (by0 >> 1) + (k >> 1);
-            if (x < fv.pyr_w[0] && y < fv.pyr_h[0]) fv.pyramid[fv.pyr_offset[0] + y * fv.pyr_w[0] + x] = q[k];
+        {
+            const uint32_t x = x0 >> 1, y = y0 >> 1;
+            if (x < fv.pyr_w[0] && y < fv.pyr_h[0]) fv.pyramid[fv.pyr_offset[0] + y * fv.pyr_w[0] + x] = m;
         }
-    }
-    uint32_t v = min(min(q[0], q[1]), min(q[2], q[3])); // level 1: one texel per thread, 16x16 per workgroup
-    if (fv.pyr_levels > 1u) {
-        const uint32_t x = bx0 >> 2, y = by0 >> 2;
-        if (x < fv.pyr_w[1] && y < fv.pyr_h[1]) fv.pyramid[fv.pyr_offset[1] + y * fv.pyr_w[1] + x] = v;
+        uint32_t v = min(m, (uint32_t)__shfl_xor((int)m, 1, 64));
+        v = min(v, (uint32_t)__shfl_xor((int)v, 32, 64));
+        if (((cp | rp) & 1u) == 0u) { // level 1: 16x16 texels per workgroup
+            lds[(rp >> 1) * 16u + (cp >> 1)] = v;
+            const uint32_t x = x0 >> 2, y = y0 >> 2;
+            if (fv.pyr_levels > 1u && x < fv.pyr_w[1] && y < fv.pyr_h[1]) fv.pyramid[fv.pyr_offset[1] + y * fv.pyr_w[1] + x] = v;
+        }
     }
     // levels 2..5: 8x8, 4x4, 2x2, 1x1 texels per workgroup, reduced through LDS
     uint32_t n = 16u; // side of the grid currently held in lds
-    lds[ty * 16u + tx] = v;
     __syncthreads();
     for (uint32_t l = 2; l <= 5u && l < fv.pyr_levels; ++l) {
         const uint32_t half = n >> 1;
@@ -2121,20 +2143,6 @@ __global__ __launch_bounds__(1024) void k_pyramid_top(FrameView fv) {
     }
 }
 
-// Between the phases: empty the work lists the early phase filled.
-__global__ __launch_bounds__(256) void k_phase_reset(FrameView fv) {
-    const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gi < fv.tiles_x * fv.tiles_y) fv.tile_count[gi] = 0u;
-    if (gi == 0) {
-        FrameCounters* c = fv.counters;
-        c->cmd_count = 0; c->vis_count = 0; c->vis_mask_count = 0; c->deferred_count = 0;
-        c->setup_count = 0; c->bin_total = 0; c->tile_nonempty = 0;
-        c->rare_barrier = 0; // the late pass's k_tile_path_rare counts its own arrivals
-    }
-    if (gi < kMidSegments) fv.counters->mid_seg[gi * 32u] = 0u;
-    if (gi < kFragSegments) fv.counters->frag_seg[gi * 16u] = 0ull;
-    if (gi < 2u * kRasterSegments) fv.counters->raster_ticket[gi / kRasterSegments][(gi % kRasterSegments) * 32u] = 0u;
-}
 
 __global__ __launch_bounds__(256) void k_clear(unsigned long long* vis, size_t n, FrameCounters* counters, uint32_t* tile_count,
                                                uint32_t n_tiles) {
@@ -2254,7 +2262,6 @@ int rdr_launch_geometry(const SceneView& sv, const FrameView& fv, hipStream_t st
         // pyramid of its depth, then everything else against the pyramid; timed with the tile path
         hipLaunchKernelGGL(k_pyramid_tiles, dim3(fv.tiles_x, fv.tiles_y), dim3(256), 0, stream, fv);
         hipLaunchKernelGGL(k_pyramid_top, dim3(1), dim3(1024), 0, stream, fv);
-        hipLaunchKernelGGL(k_phase_reset, dim3((fv.tiles_x * fv.tiles_y + 255u) / 256u), dim3(256), 0, stream, fv);
         FrameView late = fv;
         late.stat_accumulate = 1u;
         hipLaunchKernelGGL(k_draw_cull<kPhaseLate>, dim3(late.grid.draw_blocks), dim3(256), 0, stream, sv, late);

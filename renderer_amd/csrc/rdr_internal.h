@@ -125,7 +125,7 @@ struct FrameCounters {
     uint32_t tile_nonempty;   // jobs of the tile rasteriser this pass (length of tile_list)
     uint32_t mid_overflow;
     uint32_t deep_overflow;   // shadow rays whose deep (scratch) stack dropped entries without finding a hit
-    // Frame-wide (k_phase_reset leaves them alone): the RDR_FRAME_* flags of every geometry pass of the frame so far
+    // Frame-wide (the reset between the phases leaves them alone): the RDR_FRAME_* flags of every geometry pass of the frame so far
     // (with two-phase culling the early pass's list heads are gone by the time the late pass reports), and whether
     // any pass had work for the tile path or the mid-sized queue (the host's hint for the next frame's launches).
     uint32_t sticky_flags;
