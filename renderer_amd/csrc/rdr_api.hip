@@ -107,6 +107,7 @@ struct rdr_renderer {
     DeviceBuffer<rdr_material> materials;
     DeviceBuffer<float> transforms;
     DeviceBuffer<uint32_t> instance_draw;
+    DeviceBuffer<AlphaTest> draw_alpha;
     DeviceBuffer<uint8_t> draw_lod;
     DeviceBuffer<DrawFrame> draw_frame;
     DeviceBuffer<float> instance_reach;
@@ -868,6 +869,31 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
         if (pack_cubemap(tp, s.env ? &s.env->charlie : nullptr, &r->sv.charlie)) return 1;
         if (pack_cubemap(tp, s.env ? &s.env->skybox : nullptr, &r->sv.skybox)) return 1;
         if (r->images.upload(imgs.data(), imgs.size())) return 1;
+        {   // make_alpha_test (rdr_geometry.hip) for every draw, term for term
+            std::vector<AlphaTest> tests(std::max<uint32_t>(s.draw_count, 1u));
+            for (uint32_t di = 0; di < s.draw_count; ++di) {
+                const rdr_mesh_draw& d = s.mesh_draws[di];
+                AlphaTest at{};
+                at.enabled = d.alpha_mode == 1u;
+                if (at.enabled && d.material_index < s.material_count) {
+                    const rdr_material& mat = s.materials[d.material_index];
+                    at.factor_a = mat.base_color_factor[3];
+                    at.cutoff = mat.emissive_factor_alpha_cutoff[3];
+                    const uint32_t tex = mat.albedo_texture;
+                    if (tex != RDR_NO_TEXTURE && tex < s.image_count && imgs[tex].mip_count == 0u) {
+                        at.factor_a = 0.0f;
+                    } else if (tex != RDR_NO_TEXTURE && tex < s.image_count) {
+                        at.has_tex = true;
+                        at.image = tex;
+                        at.uv_set = mat.albedo_texture_uv == 0u ? 0u : 1u;
+                        at.sx = mat.albedo_texture_transform[0]; at.sy = mat.albedo_texture_transform[1];
+                        at.ox = mat.albedo_texture_transform[2]; at.oy = mat.albedo_texture_transform[3];
+                    }
+                }
+                tests[di] = at;
+            }
+            if (r->draw_alpha.upload(tests.data(), tests.size())) return 1;
+        }
         tp.blob.resize(tp.blob.size() + 16); // slack: a bilinear tap at an image's last texel reads eight bytes from it
         if (r->texels.upload(tp.blob.data(), tp.blob.size())) return 1;
         if (decode_block_images(tp, r->texels.ptr)) return 1;
@@ -897,6 +923,7 @@ int rdr_set_scene(rdr_renderer* r, const rdr_scene_desc* scene) {
     sv.materials = r->materials.ptr;
     sv.transforms = r->transforms.ptr;
     sv.instance_draw = r->instance_draw.ptr;
+    sv.draw_alpha = r->draw_alpha.ptr;
     sv.mesh_tri_area = r->mesh_tri_area.ptr;
     sv.draw_lod = r->draw_lod.ptr;
     sv.draw_frame = r->draw_frame.ptr;

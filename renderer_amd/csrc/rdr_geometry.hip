@@ -400,12 +400,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void 
 // Rasteriser
 // ------------------------------------------------------------------------------
 
-struct AlphaTest {
-    bool enabled, has_tex;
-    uint32_t image, uv_set;
-    float sx, sy, ox, oy, factor_a, cutoff;
-};
-
 // `d`: the draw, as a plain reference or through uniform_ref where the whole wave works on one draw; the material and
 // the image descriptor behind it are then scalar loads as well.
 template <typename Draw>
@@ -1185,7 +1179,7 @@ __global__ __launch_bounds__(256) void k_alpha_frag(SceneView sv, FrameView fv) 
         const uint32_t k = e & 15u, dy = k / max(r.bw, 1u), dx = k - dy * r.bw;
         const int px = (int)(r.origin & 0xFFFFu) + (int)dx, py = (int)(r.origin >> 16) + (int)dy;
         if (px >= (int)fv.width || py >= (int)fv.height || r.draw_id >= sv.draw_count) continue; // same
-        const AlphaTest at = make_alpha_test(sv, sv.draws[r.draw_id]);
+        const AlphaTest at = sv.draw_alpha[r.draw_id]; // the draw's alpha test as one record (the host's make_alpha_test), not a chain draw -> material -> image
         TriSetup<int32_t> ft;
         ft.v0 = SnapVert{}; ft.v1 = SnapVert{}; ft.v2 = SnapVert{};
         ft.v0.X = r.X[0]; ft.v1.X = r.X[1]; ft.v2.X = r.X[2];

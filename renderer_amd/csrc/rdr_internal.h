@@ -308,6 +308,14 @@ struct TriVertices {
 };
 constexpr uint32_t kTriTableStride = 128;
 
+// What the alpha test of a draw needs (make_alpha_test in rdr_geometry.hip; SceneView::draw_alpha holds the same per
+// draw, written by the host at upload, for the kernel whose lanes each work on another draw).
+struct AlphaTest {
+    bool enabled, has_tex;
+    uint32_t image, uv_set;
+    float sx, sy, ox, oy, factor_a, cutoff;
+};
+
 struct SceneView {
     const rdr_vertex* vertices;
     const float* pos_x;
@@ -330,6 +338,7 @@ struct SceneView {
     const rdr_material* materials;
     const float* transforms;
     const uint32_t* instance_draw; // meshlet instance -> draw id
+    const AlphaTest* draw_alpha;   // draw -> its alpha test
     const float* mesh_tri_area;    // per mesh: mean area of a level-0 triangle in object space (FrameView::replicate_pixels)
     const float4* instance_ball;   // per draw: see GpuInstance::outer_radius
     // Sun occluder candidates (k_sun_candidates, for one sun direction and one set of transforms): the instances
