@@ -137,6 +137,20 @@ def secondary_series(W, H, frames, instances, subdivisions):
     return out
 
 
+def camera_path(positions=120):
+    """The camera poses of the moving-camera series as (position, direction) pairs: one closed loop over the field, a
+    sideways sway of 30 units with a rise and fall of 5, a dolly of 15 units towards the field and a yaw of +-0.25 rad."""
+    import math
+    norm = math.sqrt(1.0 + 0.35 * 0.35)
+    poses = []
+    for k in range(positions):
+        a = 2.0 * math.pi * k / positions
+        yaw = 0.25 * math.sin(a)
+        poses.append(((30.0 * math.sin(a), 25.0 + 5.0 * math.sin(2.0 * a), -60.0 + 7.5 * (1.0 - math.cos(a))),
+                      (math.sin(yaw) / norm, 0.35 / norm, -math.cos(yaw) / norm)))
+    return poses
+
+
 def camera_path_series(W, H, instances, subdivisions, positions=120):
     """The field seen from a camera that moves: one closed loop of `positions` camera poses (a sideways sway of 30
     units with a rise and fall of 5, a dolly of 15 units towards the field and a yaw of +-0.25 rad), two-phase occlusion
@@ -144,17 +158,10 @@ def camera_path_series(W, H, instances, subdivisions, positions=120):
     second gives the mean (wall clock over the loop, frames queued back to back like the other series), and a third,
     on a renderer that brackets every frame's kernels with events and is read back after every frame, the spread over
     the poses: median, minimum and maximum of a frame's summed kernel time (the brackets add about 0.03 ms to a frame)."""
-    import math
     from renderer_amd import Renderer, RendererConfig, synth
     from renderer_amd.scene import Camera
     scene = synth.make_field(instances, subdivisions, lods=1, with_env=True, prepared=True)
-    norm = math.sqrt(1.0 + 0.35 * 0.35)
-    path = []
-    for k in range(positions):
-        a = 2.0 * math.pi * k / positions
-        yaw = 0.25 * math.sin(a)
-        path.append(Camera((30.0 * math.sin(a), 25.0 + 5.0 * math.sin(2.0 * a), -60.0 + 7.5 * (1.0 - math.cos(a))),
-                           (math.sin(yaw) / norm, 0.35 / norm, -math.cos(yaw) / norm)))
+    path = [Camera(pos, direction) for pos, direction in camera_path(positions)]
     r = Renderer(W, H, RendererConfig(lod_enabled=False, cull_enabled=True, collect_stats=True))
     r.set_scene(scene)
     for cam in path:

@@ -766,6 +766,35 @@ def test_secondary_field_series_4k_properties(series):
     c.close()
 
 
+def test_bench_camera_path_4k_properties():
+    """The benchmark's moving camera at its size: along the path (every eighth of its 120 poses, so that the view changes by
+    whole spheres from frame to frame) two-phase occlusion culling gives the keys and the image of the single pass bit for
+    bit, every frame is complete and its keys are valid."""
+    import bench
+    sc = synth.make_field(1250, 5, lods=1, with_env=True, prepared=True)
+    w, h = 3840, 2160
+    one = Renderer(w, h, RendererConfig(lod_enabled=False, cull_enabled=False))
+    two = Renderer(w, h, RendererConfig(lod_enabled=False, cull_enabled=True))
+    one.set_scene(sc)
+    two.set_scene(sc)
+    seen = None
+    for pos, direction in bench.camera_path(120)[::8]:
+        cam = Camera(pos, direction)
+        one.render(cam)
+        two.render(cam)
+        assert one.frame_status() == 0 and two.frame_status() == 0
+        keys = one.read_visbuffer_u64()
+        assert np.array_equal(two.read_visbuffer_u64(), keys)
+        assert np.array_equal(two.read_color(), one.read_color())
+        cov = covered(keys)
+        assert cov.sum() > w * h // 8
+        _valid_keys(sc, one, cov)
+        assert seen is None or not np.array_equal(keys, seen)  # the camera did move
+        seen = keys.copy()
+    one.close()
+    two.close()
+
+
 def _valid_keys(sc, g, cov):
     xy = g.read_visbuffer()
     draw, meshlet, tri = xy[..., 1][cov], xy[..., 0][cov] >> 8, xy[..., 0][cov] & 0xFF
